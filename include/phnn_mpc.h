@@ -1,0 +1,156 @@
+/*
+ * phnn_mpc.h -- C-ABI of the MI355X-native batched shooting-MPC rollout engine.
+ *
+ * Drop-in boundary for the hot path of Peilun-Tommy-Li/pHNN-MPC (reference paths below are relative
+ * to the reference checkout).  The reference has no FFI of its own: the boundary it exposes is the
+ * Python object protocol model(x,u) / euler_step / rollout / compute_cost / cost.backward().  Each
+ * entry point here names the reference interface it replaces; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no C++ types or exceptions cross the boundary; every function returns a phnn_status
+ *     (0 = ok, negative = error) and records a message readable with phnn_last_error();
+ *   - all tensors are contiguous row-major float32; *_dev pointers are device (HBM) addresses owned by
+ *     the caller (e.g. torch tensor.data_ptr()); the library owns only the packed weights in a handle;
+ *   - every launch is asynchronous on the hipStream_t passed as `void* stream` (NULL = default stream);
+ *     no entry point synchronises the device or allocates on the hot path;
+ *   - one handle per (model, device); calls on one handle are not re-entrant from several host threads.
+ */
+#ifndef PHNN_MPC_H
+#define PHNN_MPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHNN_MAX_N 8      /* state dimension limit  */
+#define PHNN_MAX_M 4      /* input dimension limit  */
+#define PHNN_MAX_LAYERS 4 /* hidden layers per MLP  */
+
+typedef enum {
+  PHNN_OK = 0,
+  PHNN_ERR_INVALID_ARG = -1,
+  PHNN_ERR_UNSUPPORTED = -2, /* dims / options the HIP kernels are not instantiated for */
+  PHNN_ERR_HIP = -3,
+  PHNN_ERR_ALLOC = -4
+} phnn_status;
+
+/* Dynamics model family (which reference nn.Module the handle restates). */
+typedef enum {
+  PHNN_MODEL_PHNN = 0,      /* src/pHNN.py:12-100            dx = (J-J^T-R(x)) dH/dx + G u          */
+  PHNN_MODEL_CANONICAL = 1, /* src/pHNN_canonical.py:40-273  [q,qdot] -> [q,p] -> back, cart-pole M */
+  PHNN_MODEL_ODEFUNC = 2    /* src/baseline_node.py:19-116   dx = MLP_tanh([x,u])                   */
+} phnn_model_kind;
+
+typedef enum { PHNN_INTEG_EULER = 0, PHNN_INTEG_RK4 = 1 } phnn_integrator; /* src/integrators.py:13-84 */
+
+/* MLP shape: Linear(in,h[0]) tanh ... Linear(h[depth-1],out); src/NN.py:6-40 with activation nn.Tanh,
+ * bias=True, dropout=0, layer_norm=False (the only variant any shipped config selects). */
+typedef struct {
+  int32_t depth;                   /* number of hidden layers (>=1)      */
+  int32_t hidden[PHNN_MAX_LAYERS]; /* hidden sizes                       */
+} phnn_mlp_shape;
+
+/* Model description.  The float32 weight blob passed to phnn_create() is the concatenation below, each
+ * Linear as weight (out,in) row-major followed by bias (out) -- i.e. the reference state_dict order:
+ *   PHNN      : J (n*n) | G_fixed (n*m) if fixed_G | R_net layers | H_net layers | G_net layers if !fixed_G
+ *               (src/pHNN.py:22-38; R_net out = n*n, H_net out = 1, G_net out = n*m)
+ *   CANONICAL : R_diag_raw (n) | G (n*m) | log_a, b, log_c | H_net layers
+ *               (src/pHNN_canonical.py:57-110, src/mass_matrix.py:263-268; J is the fixed canonical one)
+ *   ODEFUNC   : network layers, in = n+m, out = n (src/baseline_node.py:60-75)
+ */
+typedef struct {
+  int32_t kind;    /* phnn_model_kind */
+  int32_t n;       /* state_dim */
+  int32_t m;       /* input_dim */
+  int32_t fixed_G; /* PHNN only: 1 = G_fixed buffer, 0 = learned G_net */
+  phnn_mlp_shape h_net; /* H_net, or the ODEFunc network */
+  phnn_mlp_shape r_net; /* PHNN only */
+  phnn_mlp_shape g_net; /* PHNN with fixed_G == 0 only */
+} phnn_desc;
+
+/* Stage cost of both controllers:
+ *   cost = sum_{t=0..H} (x_t-x*)^T Q (x_t-x*) + sum_{t<H} u_t^T R u_t
+ *        + barrier_weight * sum_{t=0..H} sum_i relu(x_min_i - x_t,i)^2 + relu(x_t,i - x_max_i)^2
+ * (src/mpc_controller.py:75-114 with Q = diag, R = scalar*I; src/mpc_controller_canonical.py:91-120 with
+ * full Q, R).  Controls are clamped to [u_min,u_max] before use when has_u_bounds, and the returned
+ * gradient is w.r.t. the UNclamped controls (torch.clamp backward: pass-through on u_min<=u<=u_max,
+ * src/mpc_controller.py:180-181). */
+typedef struct {
+  float Q[PHNN_MAX_N * PHNN_MAX_N]; /* row-major n x n (leading n*n entries used) */
+  float R[PHNN_MAX_M * PHNN_MAX_M]; /* row-major m x m */
+  float x_target[PHNN_MAX_N];
+  float u_min, u_max;
+  int32_t has_u_bounds;
+  float x_min[PHNN_MAX_N], x_max[PHNN_MAX_N];
+  int32_t has_x_min, has_x_max;
+  float barrier_weight; /* reference constant: 1000 */
+} phnn_cost;
+
+typedef struct phnn_handle phnn_handle;
+
+/* Build a handle: validates the description, packs the weights into the MFMA fragment order the
+ * kernels stage into LDS, and uploads them to `device` once.  Replaces model construction +
+ * load_state_dict (src/pHNN.py:13-38, scripts/run_cartpole_mpc.py:27-54). */
+int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_floats, int device,
+                phnn_handle** out);
+int phnn_destroy(phnn_handle* h);
+/* Message of the last failing call on this handle (or of the last failing phnn_create if h == NULL). */
+const char* phnn_last_error(const phnn_handle* h);
+/* Number of float32 the weight blob for `desc` must hold; 0 if the description is invalid. */
+size_t phnn_weight_count(const phnn_desc* desc);
+
+/* model(x,u) -> (dx, H): src/pHNN.py:52-100, src/pHNN_canonical.py:172-273, src/baseline_node.py:88-116.
+ * x_dev (B,n), u_dev (B,m) -> dx_dev (B,n), H_dev (B) (H_dev may be NULL; ODEFUNC writes 0). */
+int phnn_model_forward(phnn_handle* h, const float* x_dev, const float* u_dev, int64_t B, float* dx_dev,
+                       float* H_dev, void* stream);
+
+/* Vector-Jacobian product of the dynamics, what autograd does for one model call inside
+ * cost.backward(): xbar = (df/dx)^T lam, ubar = (df/du)^T lam.  lam_dev (B,n) -> xbar_dev (B,n),
+ * ubar_dev (B,m). */
+int phnn_model_vjp(phnn_handle* h, const float* x_dev, const float* u_dev, const float* lam_dev, int64_t B,
+                   float* xbar_dev, float* ubar_dev, void* stream);
+
+/* K1 -- fused forward march: clamp, dynamics, integrator step and stage cost over the whole horizon.
+ * Replaces rollout_dynamics + compute_cost (src/mpc_controller.py:75-141), rollout + compute_cost
+ * (src/mpc_controller_canonical.py:91-161) and rollout_trajectory_differentiable (src/integrators.py:192-258).
+ *   x0_dev (B,n), u_dev (B,H,m) -> cost_dev (B), traj_dev (B,H+1,n) (may be NULL when neither the
+ *   trajectory nor a later phnn_rollout_grad is wanted). */
+int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                     const phnn_cost* cost, int32_t integrator, float dt, float* cost_dev, float* traj_dev,
+                     void* stream);
+
+/* K2 -- adjoint march: replaces cost.backward() (src/mpc_controller.py:192,
+ * src/mpc_controller_canonical.py:205).  Reads the states K1 wrote to traj_dev, re-evaluates the
+ * dynamics at each of them, and marches the costate backwards (explicit Hessian-vector product of
+ * H_net).  -> grad_u_dev (B,H,m) = d cost_b / d u_b (unclamped), grad_x0_dev (B,n) or NULL. */
+int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                      const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
+                      float* grad_u_dev, float* grad_x0_dev, void* stream);
+
+/* K3 -- Adam step on the controls, arithmetic order of torch.optim.Adam (single-tensor, defaults:
+ * no weight decay / amsgrad) as used by src/mpc_controller.py:168,200 and
+ * src/mpc_controller_canonical.py:186,206.  `step` is the 1-based step count after the increment.
+ * Optionally fuses the best-iterate tracking of src/mpc_controller_canonical.py:208-214: when
+ * best_cost_dev != NULL, rollouts whose cost_dev[b] < best_cost_dev[b] copy clamp(u_b) (the pre-step
+ * iterate that produced cost_dev) into best_u_dev and update best_cost_dev.  count = B*H*m, per = H*m. */
+int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* exp_avg_dev,
+                   float* exp_avg_sq_dev, int64_t count, float lr, float beta1, float beta2, float eps,
+                   int32_t step, const float* cost_dev, float* best_cost_dev, float* best_u_dev, int64_t per,
+                   float u_min, float u_max, int32_t has_u_bounds, void* stream);
+
+/* Introspection for benches/tests: name of the kernel variant selected for this handle, rollouts per
+ * workgroup, LDS bytes staged per workgroup. */
+int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts_per_wg,
+                     int32_t* lds_bytes, int32_t* n_workgroups_for_B, int64_t B);
+
+/* Library version (major*10000 + minor*100 + patch). */
+int phnn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHNN_MPC_H */

@@ -1,0 +1,138 @@
+"""ctypes view of include/phnn_mpc.h: the structs, and the loader of the HIP shared library.
+
+The product path has no CPU fallback: if libphnn_mpc.so is missing or a symbol is absent the import of the
+engine raises, loudly.
+"""
+import ctypes as C
+import os
+
+PHNN_MAX_N = 8
+PHNN_MAX_M = 4
+PHNN_MAX_LAYERS = 4
+
+MODEL_PHNN, MODEL_CANONICAL, MODEL_ODEFUNC = 0, 1, 2
+INTEG_EULER, INTEG_RK4 = 0, 1
+INTEGRATORS = {"euler": INTEG_EULER, "rk4": INTEG_RK4}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libphnn_mpc.so")
+
+# every symbol include/phnn_mpc.h declares
+EXPORTED = [
+    "phnn_create", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
+    "phnn_model_vjp", "phnn_rollout_fwd", "phnn_rollout_grad", "phnn_adam_step", "phnn_kernel_info",
+    "phnn_version",
+]
+
+
+class MlpShape(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("hidden", C.c_int32 * PHNN_MAX_LAYERS)]
+
+    @classmethod
+    def of(cls, hidden):
+        hidden = list(hidden)
+        if len(hidden) > PHNN_MAX_LAYERS:
+            raise ValueError(f"at most {PHNN_MAX_LAYERS} hidden layers are supported, got {len(hidden)}")
+        s = cls()
+        s.depth = len(hidden)
+        for i, h in enumerate(hidden):
+            s.hidden[i] = int(h)
+        return s
+
+
+class Desc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("fixed_G", C.c_int32),
+                ("h_net", MlpShape), ("r_net", MlpShape), ("g_net", MlpShape)]
+
+
+class Cost(C.Structure):
+    _fields_ = [("Q", C.c_float * (PHNN_MAX_N * PHNN_MAX_N)), ("R", C.c_float * (PHNN_MAX_M * PHNN_MAX_M)),
+                ("x_target", C.c_float * PHNN_MAX_N), ("u_min", C.c_float), ("u_max", C.c_float),
+                ("has_u_bounds", C.c_int32), ("x_min", C.c_float * PHNN_MAX_N), ("x_max", C.c_float * PHNN_MAX_N),
+                ("has_x_min", C.c_int32), ("has_x_max", C.c_int32), ("barrier_weight", C.c_float)]
+
+
+def make_cost(n, m, Q, R, x_target=None, u_min=None, u_max=None, x_min=None, x_max=None, barrier_weight=1000.0):
+    """Fill a phnn_cost.  Q: (n,n) matrix or length-n diagonal; R: (m,m) matrix, length-m diagonal or scalar."""
+    import numpy as np
+
+    c = Cost()
+    Q = np.asarray(Q, dtype=np.float64)
+    if Q.ndim == 1:
+        Q = np.diag(Q)
+    if Q.shape != (n, n):
+        raise ValueError(f"Q must be ({n},{n}) or ({n},), got {Q.shape}")
+    R = np.asarray(R, dtype=np.float64)
+    if R.ndim == 0:
+        R = np.eye(m) * float(R)
+    elif R.ndim == 1:
+        R = np.diag(R)
+    if R.shape != (m, m):
+        raise ValueError(f"R must be ({m},{m}), ({m},) or scalar, got {R.shape}")
+    for i in range(n):
+        for j in range(n):
+            c.Q[i * n + j] = Q[i, j]
+    for i in range(m):
+        for j in range(m):
+            c.R[i * m + j] = R[i, j]
+    xt = np.zeros(n) if x_target is None else np.asarray(x_target, dtype=np.float64).reshape(n)
+    for i in range(n):
+        c.x_target[i] = xt[i]
+    if (u_min is None) != (u_max is None):
+        # the reference only clamps when both bounds are given (src/mpc_controller.py:180-183)
+        u_min = u_max = None
+    c.has_u_bounds = int(u_min is not None)
+    c.u_min = float(u_min) if u_min is not None else 0.0
+    c.u_max = float(u_max) if u_max is not None else 0.0
+    c.has_x_min = int(x_min is not None)
+    c.has_x_max = int(x_max is not None)
+    if x_min is not None:
+        for i, v in enumerate(np.asarray(x_min, dtype=np.float64).reshape(n)):
+            c.x_min[i] = v
+    if x_max is not None:
+        for i, v in enumerate(np.asarray(x_max, dtype=np.float64).reshape(n)):
+            c.x_max[i] = v
+    c.barrier_weight = float(barrier_weight)
+    return c
+
+
+_lib = None
+
+
+def load_library():
+    """Load csrc/libphnn_mpc.so and declare the signatures of include/phnn_mpc.h.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C phnn_mpc_amd/csrc`). "
+            "There is no CPU fallback for the rollout engine.")
+    lib = C.CDLL(LIB_PATH)
+    vp, f32p, i64, i32 = C.c_void_p, C.c_void_p, C.c_int64, C.c_int32
+    lib.phnn_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.phnn_create.restype = C.c_int
+    lib.phnn_destroy.argtypes = [vp]
+    lib.phnn_destroy.restype = C.c_int
+    lib.phnn_last_error.argtypes = [vp]
+    lib.phnn_last_error.restype = C.c_char_p
+    lib.phnn_weight_count.argtypes = [C.POINTER(Desc)]
+    lib.phnn_weight_count.restype = C.c_size_t
+    lib.phnn_model_forward.argtypes = [vp, f32p, f32p, i64, f32p, f32p, vp]
+    lib.phnn_model_forward.restype = C.c_int
+    lib.phnn_model_vjp.argtypes = [vp, f32p, f32p, f32p, i64, f32p, f32p, vp]
+    lib.phnn_model_vjp.restype = C.c_int
+    lib.phnn_rollout_fwd.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, vp]
+    lib.phnn_rollout_fwd.restype = C.c_int
+    lib.phnn_rollout_grad.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, f32p, vp]
+    lib.phnn_rollout_grad.restype = C.c_int
+    lib.phnn_adam_step.argtypes = [vp, f32p, f32p, f32p, f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32,
+                                   f32p, f32p, f32p, i64, C.c_float, C.c_float, i32, vp]
+    lib.phnn_adam_step.restype = C.c_int
+    lib.phnn_kernel_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i64]
+    lib.phnn_kernel_info.restype = C.c_int
+    lib.phnn_version.argtypes = []
+    lib.phnn_version.restype = C.c_int
+    _lib = lib
+    return lib

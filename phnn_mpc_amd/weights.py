@@ -1,0 +1,124 @@
+"""state_dict -> (phnn_desc, float32 blob) packing, layout documented in include/phnn_mpc.h.
+
+The keys read here are exactly the reference's state_dict keys:
+  pHNN            J, G_fixed | G_net.net.*, R_net.net.{0,2,..}.{weight,bias}, H_net.net.*   (src/pHNN.py:22-38)
+  pHNN_Canonical  R_diag_raw, J (ignored: fixed canonical), G, M_net.{log_a,b,log_c}, H_net.net.*
+                  (src/pHNN_canonical.py:57-110)
+  ODEFunc         network.{0,2,..}.{weight,bias}                                         (src/baseline_node.py:60-75)
+Checkpoints may be a bare state_dict or {'model_state_dict': ...} (scripts/run_cartpole_mpc.py:41-44).
+"""
+import numpy as np
+
+from . import _capi
+
+
+def _np(v):
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+
+
+def unwrap_checkpoint(obj):
+    if isinstance(obj, dict) and "model_state_dict" in obj:
+        return obj["model_state_dict"]
+    return obj
+
+
+def _mlp_layers(sd, prefix):
+    """Linear layers of an nn.Sequential stored under `prefix` (indices 0,2,4,.. with Tanh between)."""
+    idx = sorted({int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix) and k.endswith(".weight")})
+    if not idx:
+        raise KeyError(f"no Linear layers under '{prefix}' in state_dict")
+    layers = []
+    for i in idx:
+        W, b = _np(sd[f"{prefix}{i}.weight"]), _np(sd[f"{prefix}{i}.bias"])
+        if W.ndim != 2 or b.shape != (W.shape[0],):
+            raise ValueError(f"{prefix}{i}: unexpected shapes {W.shape} / {b.shape}")
+        layers.append((W, b))
+    for (W0, _), (W1, _) in zip(layers[:-1], layers[1:]):
+        if W1.shape[1] != W0.shape[0]:
+            raise ValueError(f"{prefix}: layer widths do not chain ({W0.shape} -> {W1.shape}); LayerNorm/other "
+                             "layers are not supported")
+    return layers
+
+
+def _flat(layers):
+    out = []
+    for W, b in layers:
+        out += [W.ravel(), b.ravel()]
+    return out
+
+
+def detect_kind(sd):
+    keys = set(sd.keys())
+    if any(k.startswith("network.") for k in keys):
+        return _capi.MODEL_ODEFUNC
+    if "R_diag_raw" in keys:
+        return _capi.MODEL_CANONICAL
+    if "J" in keys and any(k.startswith("R_net.") for k in keys):
+        return _capi.MODEL_PHNN
+    raise ValueError("state_dict is neither a pHNN, a pHNN_Canonical nor an ODEFunc")
+
+
+def pack_state_dict(sd, kind=None, state_dim=None, input_dim=None):
+    """Return (Desc, blob) for a reference state_dict (numpy arrays or torch tensors)."""
+    sd = unwrap_checkpoint(sd)
+    if kind is None:
+        kind = detect_kind(sd)
+    d = _capi.Desc()
+    d.kind = kind
+    parts = []
+    if kind == _capi.MODEL_PHNN:
+        J = _np(sd["J"])
+        n = J.shape[0]
+        H = _mlp_layers(sd, "H_net.net.")
+        Rl = _mlp_layers(sd, "R_net.net.")
+        if H[0][0].shape[1] != n or H[-1][0].shape[0] != 1 or Rl[-1][0].shape[0] != n * n:
+            raise ValueError("pHNN state_dict: H_net/R_net shapes inconsistent with J")
+        fixed = "G_fixed" in sd
+        if fixed:
+            G = _np(sd["G_fixed"])
+            m = G.shape[1]
+            Gl = []
+        else:
+            Gl = _mlp_layers(sd, "G_net.net.")
+            m = Gl[-1][0].shape[0] // n
+        d.n, d.m, d.fixed_G = n, m, int(fixed)
+        d.h_net = _capi.MlpShape.of([W.shape[0] for W, _ in H[:-1]])
+        d.r_net = _capi.MlpShape.of([W.shape[0] for W, _ in Rl[:-1]])
+        parts.append(J.ravel())
+        if fixed:
+            parts.append(G.ravel())
+        parts += _flat(Rl) + _flat(H)
+        if not fixed:
+            d.g_net = _capi.MlpShape.of([W.shape[0] for W, _ in Gl[:-1]])
+            parts += _flat(Gl)
+    elif kind == _capi.MODEL_CANONICAL:
+        Rd = _np(sd["R_diag_raw"])
+        n = Rd.shape[0]
+        G = _np(sd["G"])
+        m = G.shape[1]
+        H = _mlp_layers(sd, "H_net.net.")
+        for k in ("M_net.log_a", "M_net.b", "M_net.log_c"):
+            if k not in sd:
+                raise ValueError("pHNN_Canonical state_dict without CartPoleMassMatrix parameters "
+                                 "(M_net.log_a/b/log_c): only mass_matrix.type == 'cartpole' is supported")
+        d.n, d.m, d.fixed_G = n, m, 1
+        d.h_net = _capi.MlpShape.of([W.shape[0] for W, _ in H[:-1]])
+        parts += [Rd.ravel(), G.ravel(),
+                  np.array([_np(sd["M_net.log_a"]).item(), _np(sd["M_net.b"]).item(), _np(sd["M_net.log_c"]).item()],
+                           np.float32)]
+        parts += _flat(H)
+    elif kind == _capi.MODEL_ODEFUNC:
+        L = _mlp_layers(sd, "network.")
+        n = L[-1][0].shape[0] if state_dim is None else int(state_dim)
+        m = L[0][0].shape[1] - n if input_dim is None else int(input_dim)
+        if L[0][0].shape[1] != n + m or L[-1][0].shape[0] != n:
+            raise ValueError("ODEFunc state_dict: first/last layer do not match (state_dim, action_dim)")
+        d.n, d.m, d.fixed_G = n, m, 1
+        d.h_net = _capi.MlpShape.of([W.shape[0] for W, _ in L[:-1]])
+        parts += _flat(L)
+    else:
+        raise ValueError(f"unknown model kind {kind}")
+    blob = np.ascontiguousarray(np.concatenate(parts).astype(np.float32))
+    return d, blob

@@ -1,0 +1,117 @@
+"""ctypes loader of oracle/libphnn_oracle.so (the CPU restatement; test infrastructure only).
+
+Builds the library with `make -C oracle` when it is missing.  Nothing under phnn_mpc_amd/ imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from phnn_mpc_amd import _capi, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "libphnn_oracle.so")
+        src = os.path.join(ORACLE_DIR, "phnn_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        _lib = C.CDLL(so)
+        for suf in ("f32", "f64"):
+            getattr(_lib, f"oracle_create_{suf}").restype = C.c_void_p
+            getattr(_lib, f"oracle_create_{suf}").argtypes = [C.POINTER(_capi.Desc), C.c_void_p, C.c_size_t]
+            getattr(_lib, f"oracle_destroy_{suf}").argtypes = [C.c_void_p]
+            getattr(_lib, f"oracle_forward_{suf}").argtypes = [C.c_void_p] * 3 + [C.c_long] + [C.c_void_p] * 2
+            getattr(_lib, f"oracle_vjp_{suf}").argtypes = [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 2
+            getattr(_lib, f"oracle_rollout_{suf}").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
+                                                               C.POINTER(_capi.Cost), C.c_int, C.c_double,
+                                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            getattr(_lib, f"oracle_adam_{suf}").argtypes = [C.c_void_p] * 4 + [C.c_long] + [C.c_double] * 4 + [C.c_int]
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleModel:
+    """One reference model restated on the CPU, in float32 ('f32') or float64 ('f64')."""
+
+    def __init__(self, state_dict, precision="f64", kind=None):
+        self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind)
+        self.suf = precision
+        self.dtype = np.float64 if precision == "f64" else np.float32
+        self.n, self.m = self.desc.n, self.desc.m
+        self.h = getattr(lib(), f"oracle_create_{precision}")(C.byref(self.desc), _ptr(self.blob), self.blob.size)
+        if not self.h:
+            raise RuntimeError("oracle_create failed (bad description / blob size)")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(lib(), f"oracle_destroy_{self.suf}")(self.h)
+            self.h = None
+
+    def _a(self, x, shape=None):
+        a = np.ascontiguousarray(np.asarray(x, dtype=self.dtype))
+        return a if shape is None else a.reshape(shape)
+
+    def forward(self, x, u):
+        x, u = self._a(x, (-1, self.n)), self._a(u, (-1, self.m))
+        B = x.shape[0]
+        dx, H = np.empty((B, self.n), self.dtype), np.empty(B, self.dtype)
+        getattr(lib(), f"oracle_forward_{self.suf}")(self.h, _ptr(x), _ptr(u), B, _ptr(dx), _ptr(H))
+        return dx, H
+
+    def vjp(self, x, u, lam):
+        x, u, lam = self._a(x, (-1, self.n)), self._a(u, (-1, self.m)), self._a(lam, (-1, self.n))
+        B = x.shape[0]
+        xb, ub = np.empty((B, self.n), self.dtype), np.empty((B, self.m), self.dtype)
+        getattr(lib(), f"oracle_vjp_{self.suf}")(self.h, _ptr(x), _ptr(u), _ptr(lam), B, _ptr(xb), _ptr(ub))
+        return xb, ub
+
+    def rollout(self, x0, U, cost, integrator, dt, grad=True, traj=True, nthreads=1):
+        x0 = self._a(x0, (-1, self.n))
+        B = x0.shape[0]
+        U = self._a(U).reshape(B, -1, self.m)
+        H = U.shape[1]
+        c = np.empty(B, self.dtype)
+        tr = np.empty((B, H + 1, self.n), self.dtype) if traj else None
+        gu = np.empty((B, H, self.m), self.dtype) if grad else None
+        gx = np.empty((B, self.n), self.dtype) if grad else None
+        integ = _capi.INTEGRATORS[integrator] if isinstance(integrator, str) else int(integrator)
+        getattr(lib(), f"oracle_rollout_{self.suf}")(self.h, _ptr(x0), _ptr(U), B, H, C.byref(cost), integ, float(dt),
+                                                     _ptr(c), _ptr(tr), _ptr(gu), _ptr(gx), int(nthreads))
+        return {"cost": c, "traj": tr, "grad_u": gu, "grad_x0": gx}
+
+    def adam(self, p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+        """In-place Adam step on arrays of self.dtype."""
+        for a in (p, g, m, v):
+            assert a.dtype == self.dtype and a.flags.c_contiguous
+        getattr(lib(), f"oracle_adam_{self.suf}")(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.size, lr, beta1, beta2, eps, step)
+
+
+def load_weights(name):
+    with np.load(os.path.join(GOLDEN, f"weights_{name}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, f"golden_{name}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+MODELS = ["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum"]
+
+
+def cost_from_golden(g, n=None, m=None, Q=None, x_target=None):
+    n = int(g["n"]) if n is None else n
+    m = int(g["m"]) if m is None else m
+    return _capi.make_cost(n, m, g["Q"] if Q is None else Q, g["R"], g["x_target"] if x_target is None else x_target,
+                           float(g["u_min"]), float(g["u_max"]))

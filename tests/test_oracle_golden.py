@@ -1,0 +1,118 @@
+"""Pin the CPU oracle (oracle/phnn_oracle.c) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py, sets G2-G4, G7, G8 of SURVEY.md 8c).
+
+The float64 oracle must reproduce the reference-in-double to round-off; the float32 oracle must agree with
+the reference-in-float32 within float32 noise (the reference's own f32-vs-f64 floor is ~1e-6 relative).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+CASES = [(1, 20), (8, 50), (4, 100), (2, 200)]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module", params=ol.MODELS)
+def bundle(request):
+    name = request.param
+    w = ol.load_weights(name)
+    return name, ol.load_golden(name), ol.OracleModel(w, "f64"), ol.OracleModel(w, "f32")
+
+
+def test_forward_f64(bundle):
+    name, g, m64, _ = bundle
+    dx, H = m64.forward(g["fwd_x"], g["fwd_u"])
+    assert rel(dx, g["fwd_dx_f64"]) < 1e-12
+    assert np.abs(H - g["fwd_H_f64"]).max() < 1e-12
+
+
+def test_forward_f32(bundle):
+    name, g, _, m32 = bundle
+    dx, H = m32.forward(g["fwd_x"], g["fwd_u"])
+    assert rel(dx, g["fwd_dx_f32"]) < 5e-6
+    assert np.abs(H - g["fwd_H_f32"]).max() < 5e-6 * max(1.0, np.abs(g["fwd_H_f32"]).max())
+
+
+def test_vjp_f64(bundle):
+    name, g, m64, _ = bundle
+    xb, ub = m64.vjp(g["vjp_x"], g["vjp_u"], g["vjp_lam"])
+    assert rel(xb, g["vjp_xbar_f64"]) < 1e-11
+    assert rel(ub, g["vjp_ubar_f64"]) < 1e-11
+
+
+def test_vjp_f32(bundle):
+    name, g, _, m32 = bundle
+    xb, ub = m32.vjp(g["vjp_x"], g["vjp_u"], g["vjp_lam"])
+    assert rel(xb, g["vjp_xbar_f32"]) < 2e-5
+    assert rel(ub, g["vjp_ubar_f32"]) < 2e-5
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+@pytest.mark.parametrize("case", CASES)
+def test_rollout_f64(bundle, integ, case):
+    name, g, m64, _ = bundle
+    B, H = case
+    key = f"roll_{integ}_B{B}_H{H}"
+    r = m64.rollout(g[key + "_x0"], g[key + "_U"], ol.cost_from_golden(g), integ, float(g["dt"]))
+    assert np.abs(r["traj"] - g[key + "_traj_f64"]).max() < 1e-10
+    assert rel(r["cost"], g[key + "_cost_f64"]) < 1e-11
+    assert rel(r["grad_u"], g[key + "_gu_f64"]) < 1e-9
+    assert rel(r["grad_x0"], g[key + "_gx0_f64"]) < 1e-9
+    # clamp mask: entries pushed outside the bounds have exactly zero gradient, the one ON the bound does not
+    U = g[key + "_U"]
+    outside = (U > float(g["u_max"])) | (U < float(g["u_min"]))
+    assert outside.any() and np.all(r["grad_u"][outside] == 0.0)
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+@pytest.mark.parametrize("case", CASES)
+def test_rollout_f32(bundle, integ, case):
+    name, g, _, m32 = bundle
+    B, H = case
+    key = f"roll_{integ}_B{B}_H{H}"
+    r = m32.rollout(g[key + "_x0"], g[key + "_U"], ol.cost_from_golden(g), integ, float(g["dt"]))
+    # tolerance stated in BASELINE.md: cost rtol 1e-5, trajectory atol 1e-5 (+rtol 1e-5), grad 1e-4*max|grad|
+    assert np.allclose(r["cost"], g[key + "_cost_f32"], rtol=1e-5, atol=0)
+    assert np.allclose(r["traj"][:, -1], g[key + "_xH_f32"], rtol=1e-5, atol=1e-5)
+    gmax = np.abs(g[key + "_gu_f32"]).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(r["grad_u"] - g[key + "_gu_f32"]) <= 1e-4 * gmax)
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_full_nonsymmetric_Q_and_target(integ):
+    g = ol.load_golden("phnn_cartpole")
+    m64 = ol.OracleModel(ol.load_weights("phnn_cartpole"), "f64")
+    cost = ol.cost_from_golden(g, Q=g["fullq_Q"], x_target=g["fullq_xt"])
+    r = m64.rollout(g["fullq_x0"], g["fullq_U"], cost, integ, 0.02)
+    assert rel(r["cost"], g[f"fullq_{integ}_cost_f64"]) < 1e-11
+    assert rel(r["grad_u"], g[f"fullq_{integ}_gu_f64"]) < 1e-9
+    assert rel(r["grad_x0"], g[f"fullq_{integ}_gx0_f64"]) < 1e-9
+
+
+def test_pendulum_anchor_g7():
+    g = ol.load_golden("phnn_pendulum")
+    w = ol.load_weights("phnn_pendulum")
+    cost = ol.cost_from_golden(g)
+    for integ in ("euler", "rk4"):
+        for prec, tol in (("f64", 1e-12), ("f32", 2e-6)):
+            m = ol.OracleModel(w, prec)
+            r = m.rollout(np.array([[0.5, 0.1]], np.float32), np.zeros((1, 10, 1)), cost, integ, 0.05)
+            assert np.abs(r["traj"] - g[f"g7_{integ}_traj_{prec}"]).max() < tol
+
+
+def test_dataset_windows_g8():
+    """Realistic magnitudes cut from data/cartpole_training_data.pt (states up to +-11, controls +-14.5)."""
+    with np.load(ol.GOLDEN + "/golden_dataset_windows.npz") as z:
+        win = {k: z[k] for k in z.files}
+    gc = ol.load_golden("phnn_cartpole")
+    for nm, wn in (("phnn", "phnn_cartpole"), ("canonical", "canonical_cartpole")):
+        m64 = ol.OracleModel(ol.load_weights(wn), "f64")
+        r = m64.rollout(win["x0"], win["U"], ol.cost_from_golden(gc), "euler", 0.02)
+        ok = win[f"{nm}_finite_f64"]
+        assert ok.all()
+        assert rel(r["cost"], win[f"{nm}_cost_f64"]) < 1e-10
+        assert rel(r["grad_u"], win[f"{nm}_gu_f64"]) < 1e-8
