@@ -1,0 +1,906 @@
+// phnn_kernels.hip.h -- device side of the MI355X (gfx950) rollout engine.
+//
+// Mapping: one 64-lane wave marches 16 rollouts through the whole horizon.  Every
+// dense layer of the small MLPs is evaluated for the 16 rollouts at once on the matrix cores with
+// v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fmaf chain), in the orientation
+//        D[unit][rollout] = sum_k W[unit][k] * act[k][rollout]
+// so that the accumulator a layer leaves in registers (lane (i,q) reg r of tile t = unit 16t+4q+r of
+// rollout i) is bit-for-bit the B operand of the next layer's MFMAs: activations never leave registers,
+// there are no transposes and no LDS round trips between layers.  Weights are the A operand and are read
+// from LDS images staged once per workgroup; one padded row-major image serves both W*a (ds_read_b128,
+// rows on lanes) and W^T*g (ds_read_b32, columns on lanes).
+//
+// Lane geometry inside a wave:  i = lane & 15 (rollout / A-row / D-column),  q = lane >> 4 (k-slot / D-row
+// group).  Per-rollout small vectors (state, costate, dH, ...) are held redundantly by the 4 lanes
+// (i, q=0..3) of a rollout as f32x4 "all components in every lane".
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/phnn_mpc.h"
+
+#define DEV __device__ __forceinline__
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int kTileB = 16;       // rollouts per wave
+constexpr int kMaxWaves = 8;     // waves per workgroup (2 per SIMD)
+constexpr int kScrFloats = 16 * 20;  // per-wave LDS scratch: 16 rollouts x (16 + 4 pad) floats
+
+struct Lane {
+  int lane, i, q;
+};
+
+template <int T>
+struct Act {
+  f32x4 v[T];
+};
+
+DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+DEV f32x4 splat4(float s) { return f32x4{s, s, s, s}; }
+
+DEV float sel4(f32x4 v, int q) { return q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : v[3])); }
+
+// tanh in float32: odd minimax polynomial below 0.4 (rel. error 6e-8), 1 - 2/(1+e^{2|x|}) above
+// (abs. error ~1e-7), see DESIGN.md "numerics".
+DEV float tanh_dev(float x) {
+  float ax = __builtin_fabsf(x);
+  float s = x * x;
+  float p = -0.007265716325491667f;
+  p = __builtin_fmaf(p, s, 0.021598778665065765f);
+  p = __builtin_fmaf(p, s, -0.053949106484651566f);
+  p = __builtin_fmaf(p, s, 0.13333284854888916f);
+  p = __builtin_fmaf(p, s, -0.3333333432674408f);
+  float small = __builtin_fmaf(ax * s, p, ax);
+  float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);
+  float big = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+  float r = ax < 0.4f ? small : big;
+  return __builtin_copysignf(r, x);
+}
+
+// sin and cos in float32: 3-term Cody-Waite reduction by pi/2 (exact first step through the fma) and
+// degree-3 minimax polynomials in r^2; abs. error < 1e-7 for |x| < 3000.  (ocml sincosf carries a
+// Payne-Hanek path whose scratch array would put every wave's registers on the stack.)
+DEV void sincos_dev(float x, float& sn, float& cs) {
+  float k = __builtin_rintf(x * 0.6366197723675814f);
+  float r = __builtin_fmaf(k, -1.5707963705062866f, x);
+  r = __builtin_fmaf(k, 4.371138828673793e-08f, r);
+  r = __builtin_fmaf(k, 1.7763568394002505e-15f, r);
+  float r2 = r * r;
+  float p = 2.723737452470232e-06f;
+  p = __builtin_fmaf(p, r2, -0.00019839986634906381f);
+  p = __builtin_fmaf(p, r2, 0.008333331905305386f);
+  p = __builtin_fmaf(p, r2, -0.1666666716337204f);
+  float s0 = __builtin_fmaf(r * r2, p, r);
+  float q = -2.721424721130461e-07f;
+  q = __builtin_fmaf(q, r2, 2.479966133250855e-05f);
+  q = __builtin_fmaf(q, r2, -0.0013888884568586946f);
+  q = __builtin_fmaf(q, r2, 0.0416666679084301f);
+  float c0 = __builtin_fmaf(r2 * r2, q, __builtin_fmaf(-0.5f, r2, 1.0f));
+  int n = (int)k;
+  float ss = (n & 1) ? c0 : s0;
+  float cc = (n & 1) ? s0 : c0;
+  sn = (n & 2) ? -ss : ss;
+  cs = ((n + 1) & 2) ? -cc : cc;
+}
+
+// The weight images in LDS never change after staging, so without this the compiler hoists their loads
+// out of the time loop (and CSEs them across the evaluations of one step) into registers it does not
+// have, and spills.  A compiler-only memory barrier at the start of each dynamics evaluation keeps
+// the reads where they are consumed.
+DEV void keep_lds_reads_local() { asm volatile("" ::: "memory"); }
+
+template <int T>
+DEV void tanh_act(Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.v[t][r] = tanh_dev(a.v[t][r]);
+}
+
+// o[t] = vec[16t + 4q .. +3]  (vector in natural unit order in LDS: bias, output weights)
+template <int T>
+DEV void load_vec(Act<T>& o, const float* vec, Lane ln) {
+  keep_lds_reads_local();
+#pragma unroll
+  for (int t = 0; t < T; ++t) o.v[t] = *reinterpret_cast<const f32x4*>(vec + 16 * t + 4 * ln.q);
+}
+
+template <int T>
+DEV void zero_act(Act<T>& o) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) o.v[t] = splat4(0.f);
+}
+
+// in(<=4) -> 16T units, one k-step.  Wf is the fragment image [T][64]: lane (i,q) holds W[16nt+i][q].
+template <int T>
+DEV void in_layer(Act<T>& o, const float* Wf, Lane ln, float xk) {
+  keep_lds_reads_local();
+#pragma unroll
+  for (int nt = 0; nt < T; ++nt) o.v[nt] = mfma(Wf[nt * 64 + ln.lane], xk, o.v[nt]);
+}
+
+// o += W * in : W is a padded row-major image [16*TO][LD], LD = 16*TI + 4.
+template <int TO, int TI>
+DEV void sq_fwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
+  constexpr int LD = 16 * TI + 4;
+  keep_lds_reads_local();
+  const float* base = W + ln.i * LD + 4 * ln.q;
+  constexpr int G = TO < 4 ? TO : 4;  // output tiles in flight: 4 independent accumulation chains
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+#pragma unroll
+    for (int n0 = 0; n0 < TO; n0 += G) {
+      f32x4 a[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4*>(base + (n0 + g) * 16 * LD + 16 * t);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < G; ++g) o.v[n0 + g] = mfma(a[g][r], in.v[t][r], o.v[n0 + g]);
+    }
+  }
+}
+
+// o += W^T * in : same image [16*TI][LD], LD = 16*TO + 4 (TO = tiles of the columns of W).
+template <int TO, int TI>
+DEV void sq_bwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
+  constexpr int LD = 16 * TO + 4;
+  keep_lds_reads_local();
+  const float* base = W + 4 * ln.q * LD + ln.i;
+#pragma unroll
+  for (int t = 0; t < TI; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int nt = 0; nt < TO; ++nt) o.v[nt] = mfma(base[(16 * t + r) * LD + 16 * nt], in.v[t][r], o.v[nt]);
+}
+
+// 16*TI units -> 4 outputs, every lane receives all 4 (row 4q+r of the MFMA tile carries output r).
+// Wt is [4][LR], LR = 16*TI + 8, row c = weights of output c.
+template <int TI>
+DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
+  constexpr int LR = 16 * TI + 8;
+  keep_lds_reads_local();
+  const float* base = Wt + (ln.i & 3) * LR + 4 * ln.q;
+  f32x4 o0 = splat4(0.f), o1 = splat4(0.f);
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(base + 16 * t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if ((t & 1) == 0) o0 = mfma(a[r], in.v[t][r], o0);
+      else o1 = mfma(a[r], in.v[t][r], o1);
+    }
+  }
+  return o0 + o1;
+}
+
+// 16 per-rollout values spread over the 4 lanes of a rollout (lane (i,q) holds values 4q..4q+3) ->
+// all 16 in every lane, through the wave's LDS scratch (in-order per wave, no barrier needed).
+DEV void gather16(float* scr, Lane ln, f32x4 mine, float (&out)[16]) {
+  float* row = scr + ln.i * 20;
+  *reinterpret_cast<f32x4*>(row + 4 * ln.q) = mine;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * k);
+    out[4 * k + 0] = v[0];
+    out[4 * k + 1] = v[1];
+    out[4 * k + 2] = v[2];
+    out[4 * k + 3] = v[3];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+DEV float reduce_q(float v) {  // sum over the 4 lanes (q = 0..3) of a rollout
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS image layouts (offsets in floats; every section size is a multiple of 4 floats)
+// ------------------------------------------------------------------------------------------------
+template <int HID>
+struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
+  static constexpr int T = HID / 16, LD = HID + 4, LR = HID + 8;
+  static constexpr int oW2 = 0;                  // [HID][LD]
+  static constexpr int oW1f = oW2 + HID * LD;    // [T][64] fragment image of W1
+  static constexpr int oB1 = oW1f + T * 64;      // [HID]
+  static constexpr int oB2 = oB1 + HID;          // [HID]
+  static constexpr int oW3 = oB2 + HID;          // [HID]
+  static constexpr int oW1T = oW3 + HID;         // [4][LR] rows c = W1[:,c]
+  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 0, 0, 0)
+  static constexpr int SIZE = oB3 + 4;
+};
+
+template <int HID>
+struct LayH1 {  // in(<=4) -> HID -> out(<=16)  (R_net, G_net)
+  static constexpr int T = HID / 16, LD = HID + 4, LR = HID + 8;
+  static constexpr int oV2 = 0;                 // [16][LD]
+  static constexpr int oV1f = oV2 + 16 * LD;    // [T][64]
+  static constexpr int oC1 = oV1f + T * 64;     // [HID]
+  static constexpr int oC2 = oC1 + HID;         // [16]
+  static constexpr int oV1T = oC2 + 16;         // [4][LR]
+  static constexpr int SIZE = oV1T + 4 * LR;
+};
+
+// ------------------------------------------------------------------------------------------------
+// H_net: value, gradient and Hessian-vector product (src/pHNN.py:72-73, src/pHNN_canonical.py:208-215)
+// ------------------------------------------------------------------------------------------------
+template <int HID>
+struct HTape {
+  Act<HID / 16> a1, a2, q1;  // activations, and q1 = W2^T g2 (before the (1-a1^2) factor)
+};
+
+template <int HID, bool WANT_H>
+DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hval) {
+  using Y = LayH2<HID>;
+  constexpr int T = Y::T;
+  load_vec<T>(tp.a1, L + Y::oB1, ln);
+  in_layer<T>(tp.a1, L + Y::oW1f, ln, sel4(z, ln.q));
+  tanh_act<T>(tp.a1);
+  load_vec<T>(tp.a2, L + Y::oB2, ln);
+  sq_fwd<T, T>(tp.a2, L + Y::oW2, ln, tp.a1);
+  tanh_act<T>(tp.a2);
+  Act<T> g;
+  float s = 0.f;
+  keep_lds_reads_local();
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * t + 4 * ln.q);
+    if (WANT_H) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s = __builtin_fmaf(w3[r], tp.a2.v[t][r], s);
+    }
+    g.v[t] = w3 * (1.0f - tp.a2.v[t] * tp.a2.v[t]);
+  }
+  if (WANT_H) Hval = reduce_q(s) + L[Y::oB3];
+  zero_act<T>(tp.q1);
+  sq_bwd<T, T>(tp.q1, L + Y::oW2, ln, g);
+#pragma unroll
+  for (int t = 0; t < T; ++t) g.v[t] = tp.q1.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
+  return to4_rep<T>(L + Y::oW1T, ln, g);
+}
+
+// Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
+// (q1 is overwritten) to keep the live register set at five activation vectors.
+template <int HID>
+DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
+  using Y = LayH2<HID>;
+  constexpr int T = Y::T;
+  Act<T> ad1, w;
+  zero_act<T>(ad1);
+  in_layer<T>(ad1, L + Y::oW1f, ln, sel4(v, ln.q));
+#pragma unroll
+  for (int t = 0; t < T; ++t) ad1.v[t] = (1.0f - tp.a1.v[t] * tp.a1.v[t]) * ad1.v[t];
+  zero_act<T>(w);
+  sq_fwd<T, T>(w, L + Y::oW2, ln, ad1);
+  // second term of gdot1 = qdot1*(1-a1^2) + q1*(-2 a1 adot1): fold it now, adot1 dies here
+#pragma unroll
+  for (int t = 0; t < T; ++t) tp.q1.v[t] = tp.q1.v[t] * (-2.0f * tp.a1.v[t] * ad1.v[t]);
+  keep_lds_reads_local();
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * t + 4 * ln.q);
+    f32x4 a2 = tp.a2.v[t];
+    f32x4 ad2 = (1.0f - a2 * a2) * w.v[t];
+    w.v[t] = w3 * (-2.0f * a2 * ad2);  // gdot2
+  }
+  Act<T> qd;
+  zero_act<T>(qd);
+  sq_bwd<T, T>(qd, L + Y::oW2, ln, w);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 a1 = tp.a1.v[t];
+    qd.v[t] = qd.v[t] * (1.0f - a1 * a1) + tp.q1.v[t];
+  }
+  return to4_rep<T>(L + Y::oW1T, ln, qd);
+}
+
+// one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations
+template <int HID>
+DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, float (&out)[16]) {
+  using Y = LayH1<HID>;
+  constexpr int T = Y::T;
+  load_vec<T>(h, L + Y::oC1, ln);
+  in_layer<T>(h, L + Y::oV1f, ln, sel4(x, ln.q));
+  tanh_act<T>(h);
+  Act<1> o;
+  o.v[0] = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
+  sq_fwd<1, T>(o, L + Y::oV2, ln, h);
+  gather16(scr, ln, o.v[0], out);
+}
+
+// xbar = (d net / d x)^T obar, obar given as all 16 values in every lane
+template <int HID>
+DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&obar)[16]) {
+  using Y = LayH1<HID>;
+  constexpr int T = Y::T;
+  Act<1> ob;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    ob.v[0][r] = ln.q == 0 ? obar[r] : (ln.q == 1 ? obar[4 + r] : (ln.q == 2 ? obar[8 + r] : obar[12 + r]));
+  Act<T> hb;
+  zero_act<T>(hb);
+  sq_bwd<T, 1>(hb, L + Y::oV2, ln, ob);
+#pragma unroll
+  for (int t = 0; t < T; ++t) hb.v[t] = hb.v[t] * (1.0f - h.v[t] * h.v[t]);
+  return to4_rep<T>(L + Y::oV1T, ln, hb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Model: pHNN (src/pHNN.py:52-100)
+// ------------------------------------------------------------------------------------------------
+template <int N_, int HID_, bool FIXG_>
+struct PhnnModel {
+  static constexpr int N = N_, HID = HID_, T = HID / 16;
+  static constexpr bool FIXG = FIXG_;
+  static constexpr int oH = 0;
+  static constexpr int oR = oH + LayH2<HID>::SIZE;
+  static constexpr int oGn = oR + LayH1<HID>::SIZE;
+  static constexpr int oJ = oGn + (FIXG ? 0 : LayH1<HID>::SIZE);  // [16] J - J^T, row-major N x N
+  static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
+  static constexpr int IMG = oG + 4;
+
+  // dx = (Jeff - S S^T) dH + G u, with S = sym(R_raw)
+  template <bool WANT_H>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval) {
+    keep_lds_reads_local();
+    HTape<HID> tp;
+    f32x4 dH = hnet_grad<HID, WANT_H>(L + oH, ln, x, tp, Hval);
+    Act<T> hR;
+    float rf[16];
+    h1_fwd<HID>(L + oR, scr, ln, x, hR, rf);
+    float G[N];
+    if (FIXG) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) G[i] = L[oG + i];
+    } else {
+      Act<T> hG;
+      float gf[16];
+      h1_fwd<HID>(L + oGn, scr, ln, x, hG, gf);
+#pragma unroll
+      for (int i = 0; i < N; ++i) G[i] = gf[i];
+    }
+    return combine(L, rf, dH, G, u);
+  }
+
+  DEV static f32x4 combine(const float* L, const float (&rf)[16], f32x4 dH, const float (&G)[N], float u) {
+    float S[N][N], StdH[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) S[i][j] = (rf[i * N + j] + rf[j * N + i]) * 0.5f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) a = __builtin_fmaf(S[i][k], dH[i], a);
+      StdH[k] = a;
+    }
+    f32x4 dx = splat4(0.f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc = __builtin_fmaf(L[oJ + i * N + j], dH[j], acc);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[i][k], StdH[k], acc);
+      dx[i] = __builtin_fmaf(G[i], u, acc);
+    }
+    return dx;
+  }
+
+  // xbar = (df/dx)^T lam, ubar = (df/du)^T lam at (x,u); recomputes the forward tape it needs.
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar) {
+    keep_lds_reads_local();
+    HTape<HID> tp;
+    float Hdummy;
+    f32x4 dH = hnet_grad<HID, false>(L + oH, ln, x, tp, Hdummy);
+    f32x4 xb = splat4(0.f);
+    float S[N][N], Stl[N], StdH[N];
+    {
+      Act<T> hR;
+      float rf[16];
+      h1_fwd<HID>(L + oR, scr, ln, x, hR, rf);
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) S[i][j] = (rf[i * N + j] + rf[j * N + i]) * 0.5f;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          a = __builtin_fmaf(S[i][k], lam[i], a);
+          c = __builtin_fmaf(S[i][k], dH[i], c);
+        }
+        Stl[k] = a;
+        StdH[k] = c;
+      }
+      // dissipation term: Sbar = -(lam (S^T dH)^T + dH (S^T lam)^T), R_raw_bar = (Sbar + Sbar^T)/2
+      float rbar[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) rbar[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          float sij = -(lam[i] * StdH[j] + dH[i] * Stl[j]);
+          float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
+          rbar[i * N + j] = (sij + sji) * 0.5f;
+        }
+      xb += h1_bwd<HID>(L + oR, ln, hR, rbar);
+    }
+    ubar = 0.f;
+    if (FIXG) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) ubar = __builtin_fmaf(L[oG + i], lam[i], ubar);
+    } else {
+      Act<T> hG;
+      float gf[16], gbar[16];
+      h1_fwd<HID>(L + oGn, scr, ln, x, hG, gf);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) gbar[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        ubar = __builtin_fmaf(gf[i], lam[i], ubar);
+        gbar[i] = lam[i] * u;
+      }
+      xb += h1_bwd<HID>(L + oGn, ln, hG, gbar);
+    }
+    // v = A^T lam, A = Jeff - S S^T
+    f32x4 v = splat4(0.f);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc = __builtin_fmaf(L[oJ + i * N + j], lam[i], acc);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[j][k], Stl[k], acc);
+      v[j] = acc;
+    }
+    xbar = xb + hnet_hvp<HID>(L + oH, ln, tp, v);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Model: canonical pHNN with the cart-pole mass matrix (src/pHNN_canonical.py:172-273,
+// src/mass_matrix.py:270-362, src/coordinate_transforms.py:20-130)
+// ------------------------------------------------------------------------------------------------
+template <int HID_>
+struct CanonModel {
+  static constexpr int N = 4, HID = HID_, T = HID / 16;
+  static constexpr int oH = 0;
+  static constexpr int oC = oH + LayH2<HID>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
+  static constexpr int IMG = oC + 12;
+
+  template <bool WANT_H>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, float u, float& Hval) {
+    keep_lds_reads_local();
+    float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
+    float sn, cs;
+    sincos_dev(y[1], sn, cs);
+    float bc = b * cs;
+    f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
+    HTape<HID> tp;
+    f32x4 dH = hnet_grad<HID, WANT_H>(L + oH, ln, z, tp, Hval);
+    float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + L[oC + 10] * u;
+    float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + L[oC + 11] * u;
+    float det = (a * c - bc * bc) + 1e-6f;
+    float mi00 = c / det, mi01 = -bc / det, mi11 = a / det;
+    return f32x4{mi00 * z[2] + mi01 * z[3], mi01 * z[2] + mi11 * z[3], mi00 * dp0 + mi01 * dp1,
+                 mi01 * dp0 + mi11 * dp1};
+  }
+
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, float u, f32x4 lam, f32x4& ybar, float& ubar) {
+    keep_lds_reads_local();
+    float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
+    float sn, cs;
+    sincos_dev(y[1], sn, cs);
+    float bc = b * cs;
+    f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
+    HTape<HID> tp;
+    float Hdummy;
+    f32x4 dH = hnet_grad<HID, false>(L + oH, ln, z, tp, Hdummy);
+    float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
+    float dp0 = (-dH[0] - Rd2 * dH[2]) + L[oC + 10] * u;
+    float dp1 = (-dH[1] - Rd3 * dH[3]) + L[oC + 11] * u;
+    float det = (a * c - bc * bc) + 1e-6f;
+    float rdet = 1.0f / det;
+    float mi00 = c * rdet, mi01 = -bc * rdet, mi11 = a * rdet;
+    float pb0 = lam[0] * mi00 + lam[1] * mi01, pb1 = lam[0] * mi01 + lam[1] * mi11;
+    float dpb0 = lam[2] * mi00 + lam[3] * mi01, dpb1 = lam[2] * mi01 + lam[3] * mi11;
+    float mb00 = lam[0] * z[2] + lam[2] * dp0;
+    float mb01 = lam[0] * z[3] + lam[1] * z[2] + lam[2] * dp1 + lam[3] * dp0;
+    float mb11 = lam[1] * z[3] + lam[3] * dp1;
+    f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
+    ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
+    f32x4 zb = hnet_hvp<HID>(L + oH, ln, tp, v);
+    zb[2] += pb0;
+    zb[3] += pb1;
+    float bcb = zb[2] * y[3] + zb[3] * y[2];
+    float detb = (-(mb00 * c + mb11 * a) + mb01 * bc) * (rdet * rdet);
+    bcb += -mb01 * rdet;
+    bcb += -2.0f * bc * detb;
+    ybar = f32x4{zb[0], zb[1] + bcb * (-b * sn), zb[2] * a + zb[3] * bc, zb[2] * bc + zb[3] * c};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Model: ODEFunc MLP [x,u] -> HID -> HID -> HID -> n  (src/baseline_node.py:60-116), n + m <= 4
+// ------------------------------------------------------------------------------------------------
+template <int N_, int HID_>
+struct OdeModel {
+  static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8;
+  static constexpr int oW1f = 0;                   // [T][64]   W1 (HID x (n+m))
+  static constexpr int oB1 = oW1f + T * 64;        // [HID]
+  static constexpr int oW2 = oB1 + HID;            // [HID][LD]
+  static constexpr int oB2 = oW2 + HID * LD;
+  static constexpr int oW3 = oB2 + HID;            // [HID][LD]
+  static constexpr int oB3 = oW3 + HID * LD;
+  static constexpr int oW4r = oB3 + HID;           // [4][LR] rows c = W4[c,:]
+  static constexpr int oB4 = oW4r + 4 * LR;        // [4]
+  static constexpr int oW4f = oB4 + 4;             // [T][64] fragment image of W4^T (HID x n)
+  static constexpr int oW1T = oW4f + T * 64;       // [4][LR] rows c = W1[:,c]
+  static constexpr int IMG = oW1T + 4 * LR;
+
+  struct Tape {
+    Act<T> a1, a2, a3;
+  };
+
+  DEV static f32x4 fwd(const float* L, Lane ln, f32x4 x, float u, Tape& tp) {
+    keep_lds_reads_local();
+    f32x4 in = x;
+    in[N] = u;  // N + 1 <= 4
+    load_vec<T>(tp.a1, L + oB1, ln);
+    in_layer<T>(tp.a1, L + oW1f, ln, sel4(in, ln.q));
+    tanh_act<T>(tp.a1);
+    load_vec<T>(tp.a2, L + oB2, ln);
+    sq_fwd<T, T>(tp.a2, L + oW2, ln, tp.a1);
+    tanh_act<T>(tp.a2);
+    load_vec<T>(tp.a3, L + oB3, ln);
+    sq_fwd<T, T>(tp.a3, L + oW3, ln, tp.a2);
+    tanh_act<T>(tp.a3);
+    f32x4 b4 = *reinterpret_cast<const f32x4*>(L + oB4);
+    return to4_rep<T>(L + oW4r, ln, tp.a3) + b4;
+  }
+
+  template <bool WANT_H>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval) {
+    Tape tp;
+    if (WANT_H) Hval = 0.f;
+    return fwd(L, ln, x, u, tp);
+  }
+
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar) {
+    Tape tp;
+    (void)fwd(L, ln, x, u, tp);
+    Act<T> d, e;
+    zero_act<T>(d);
+    in_layer<T>(d, L + oW4f, ln, sel4(lam, ln.q));
+#pragma unroll
+    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * (1.0f - tp.a3.v[t] * tp.a3.v[t]);
+    zero_act<T>(e);
+    sq_bwd<T, T>(e, L + oW3, ln, d);
+#pragma unroll
+    for (int t = 0; t < T; ++t) e.v[t] = e.v[t] * (1.0f - tp.a2.v[t] * tp.a2.v[t]);
+    zero_act<T>(d);
+    sq_bwd<T, T>(d, L + oW2, ln, e);
+#pragma unroll
+    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
+    f32x4 inb = to4_rep<T>(L + oW1T, ln, d);
+    ubar = inb[N];
+    inb[N] = 0.f;
+    xbar = inb;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// stage cost (src/mpc_controller.py:75-114, src/mpc_controller_canonical.py:91-120)
+// ------------------------------------------------------------------------------------------------
+template <int N>
+DEV float state_cost(const phnn_cost& c, f32x4 x) {
+  float e[N], cost = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = x[i] - c.x_target[i];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s = __builtin_fmaf(e[i], c.Q[i * N + j], s);
+    cost = __builtin_fmaf(s, e[j], cost);
+  }
+  if (c.has_x_min) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float v = fmaxf(c.x_min[i] - x[i], 0.f);
+      s = __builtin_fmaf(v, v, s);
+    }
+    cost = __builtin_fmaf(c.barrier_weight, s, cost);
+  }
+  if (c.has_x_max) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float v = fmaxf(x[i] - c.x_max[i], 0.f);
+      s = __builtin_fmaf(v, v, s);
+    }
+    cost = __builtin_fmaf(c.barrier_weight, s, cost);
+  }
+  return cost;
+}
+
+template <int N>
+DEV f32x4 state_cost_grad(const phnn_cost& c, f32x4 x) {
+  float e[N];
+  f32x4 g = splat4(0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = x[i] - c.x_target[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < N; ++j) s = __builtin_fmaf(c.Q[i * N + j] + c.Q[j * N + i], e[j], s);
+    if (c.has_x_min) s = __builtin_fmaf(-2.0f * c.barrier_weight, fmaxf(c.x_min[i] - x[i], 0.f), s);
+    if (c.has_x_max) s = __builtin_fmaf(2.0f * c.barrier_weight, fmaxf(x[i] - c.x_max[i], 0.f), s);
+    g[i] = s;
+  }
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct RollParams {
+  const float* img;    // packed LDS image (global)
+  const float* x0;     // (B,N)
+  const float* u;      // (B,H)   (m = 1)
+  const float* traj_in;  // (B,H+1,N)  K2
+  float* cost;         // (B)
+  float* traj;         // (B,H+1,N) or null
+  float* grad_u;       // (B,H)
+  float* grad_x0;      // (B,N) or null
+  long long B;
+  int H;
+  float dt, half_dt, sixth_dt;
+  phnn_cost c;
+};
+
+struct PointParams {
+  const float* img;
+  const float* x;    // (B,N)
+  const float* u;    // (B)
+  const float* lam;  // (B,N)  vjp only
+  float* dx;         // (B,N)  forward: dx ; vjp: xbar
+  float* Hout;       // (B)    forward: H (nullable) ; vjp: ubar
+  long long B;
+};
+
+template <int IMG>
+DEV void stage_image(float* lds, const float* img) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(img);
+  f32x4* dst = reinterpret_cast<f32x4*>(lds);
+  for (int k = threadIdx.x; k < IMG / 4; k += blockDim.x) dst[k] = src[k];
+  __syncthreads();
+}
+
+template <int N>
+DEV f32x4 load_state(const float* p) {
+  if (N == 4) return *reinterpret_cast<const f32x4*>(p);
+  f32x4 x = splat4(0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = p[i];
+  return x;
+}
+template <int N>
+DEV void store_state(float* p, f32x4 x) {
+  if (N == 4) {
+    *reinterpret_cast<f32x4*>(p) = x;
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = x[i];
+  }
+}
+
+DEV float clamp_u(const phnn_cost& c, float u) { return c.has_u_bounds ? fminf(fmaxf(u, c.u_min), c.u_max) : u; }
+
+// K1: forward march.  One wave = 16 rollouts; grid x = ceil(B/16/waves).
+template <class M, int INTEG>
+__global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int N = M::N;
+  stage_image<M::IMG>(lds, p.img);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  Lane ln;
+  ln.lane = threadIdx.x & 63;
+  ln.i = ln.lane & 15;
+  ln.q = ln.lane >> 4;
+  float* scr = lds + M::IMG + wave * kScrFloats;
+  const long long tile = (long long)blockIdx.x * nwaves + wave;
+  if (tile * kTileB >= p.B) return;
+  long long b = tile * kTileB + ln.i;
+  const bool valid = b < p.B;
+  if (!valid) b = p.B - 1;
+  const float* L = lds;
+  f32x4 x = load_state<N>(p.x0 + b * N);
+  const bool writer = valid && ln.q == 0;
+  if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1)) * N, x);
+  float cost = state_cost<N>(p.c, x);
+  const float* up = p.u + b * p.H;
+  float Hd;
+  for (int t = 0; t < p.H; ++t) {
+    float u = clamp_u(p.c, up[t]);
+    cost = __builtin_fmaf(u * p.c.R[0], u, cost);
+    f32x4 k1 = M::template f<false>(L, scr, ln, x, u, Hd);
+    if (INTEG == PHNN_INTEG_EULER) {
+      x = x + p.dt * k1;
+    } else {
+      f32x4 k2 = M::template f<false>(L, scr, ln, x + p.half_dt * k1, u, Hd);
+      f32x4 k3 = M::template f<false>(L, scr, ln, x + p.half_dt * k2, u, Hd);
+      f32x4 k4 = M::template f<false>(L, scr, ln, x + p.dt * k3, u, Hd);
+      x = x + p.sixth_dt * (((k1 + 2.0f * k2) + 2.0f * k3) + k4);
+    }
+    cost += state_cost<N>(p.c, x);
+    if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1) + t + 1) * N, x);
+  }
+  if (writer) p.cost[b] = cost;
+}
+
+// K2: adjoint march over the states K1 stored.
+template <class M, int INTEG>
+__global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int N = M::N;
+  stage_image<M::IMG>(lds, p.img);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  Lane ln;
+  ln.lane = threadIdx.x & 63;
+  ln.i = ln.lane & 15;
+  ln.q = ln.lane >> 4;
+  float* scr = lds + M::IMG + wave * kScrFloats;
+  const long long tile = (long long)blockIdx.x * nwaves + wave;
+  if (tile * kTileB >= p.B) return;
+  long long b = tile * kTileB + ln.i;
+  const bool valid = b < p.B;
+  if (!valid) b = p.B - 1;
+  const float* L = lds;
+  const bool writer = valid && ln.q == 0;
+  const float* tr = p.traj_in + (b * (p.H + 1)) * N;
+  const float* up = p.u + b * p.H;
+  f32x4 lam = state_cost_grad<N>(p.c, load_state<N>(tr + (long long)p.H * N));
+  float Hd;
+  for (int t = p.H - 1; t >= 0; --t) {
+    f32x4 x = load_state<N>(tr + (long long)t * N);
+    float uraw = up[t];
+    float u = clamp_u(p.c, uraw);
+    f32x4 xb;
+    float ub, utot;
+    if (INTEG == PHNN_INTEG_EULER) {
+      M::vjp(L, scr, ln, x, u, p.dt * lam, xb, ub);
+      lam = lam + xb;
+      utot = ub;
+    } else {
+      f32x4 k1 = M::template f<false>(L, scr, ln, x, u, Hd);
+      f32x4 y2 = x + p.half_dt * k1;
+      f32x4 k2 = M::template f<false>(L, scr, ln, y2, u, Hd);
+      f32x4 y3 = x + p.half_dt * k2;
+      f32x4 k3 = M::template f<false>(L, scr, ln, y3, u, Hd);
+      f32x4 y4 = x + p.dt * k3;
+      f32x4 yb4, yb3, yb2, yb1;
+      M::vjp(L, scr, ln, y4, u, p.sixth_dt * lam, yb4, ub);
+      utot = ub;
+      M::vjp(L, scr, ln, y3, u, (2.0f * p.sixth_dt) * lam + p.dt * yb4, yb3, ub);
+      utot += ub;
+      M::vjp(L, scr, ln, y2, u, (2.0f * p.sixth_dt) * lam + p.half_dt * yb3, yb2, ub);
+      utot += ub;
+      M::vjp(L, scr, ln, x, u, p.sixth_dt * lam + p.half_dt * yb2, yb1, ub);
+      utot += ub;
+      lam = lam + yb1 + yb2 + yb3 + yb4;
+    }
+    lam = lam + state_cost_grad<N>(p.c, x);
+    float g = __builtin_fmaf(2.0f * p.c.R[0], u, utot);
+    if (p.c.has_u_bounds && !(uraw >= p.c.u_min && uraw <= p.c.u_max)) g = 0.f;
+    if (writer) p.grad_u[b * p.H + t] = g;
+  }
+  if (p.grad_x0 && writer) store_state<N>(p.grad_x0 + b * N, lam);
+}
+
+// model(x,u) -> (dx, H)
+template <class M>
+__global__ __launch_bounds__(64 * kMaxWaves) void k_model_forward(PointParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int N = M::N;
+  stage_image<M::IMG>(lds, p.img);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  Lane ln;
+  ln.lane = threadIdx.x & 63;
+  ln.i = ln.lane & 15;
+  ln.q = ln.lane >> 4;
+  float* scr = lds + M::IMG + wave * kScrFloats;
+  const long long ntiles = (p.B + kTileB - 1) / kTileB;
+  for (long long tile = (long long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long long)gridDim.x * nwaves) {
+    long long b = tile * kTileB + ln.i;
+    const bool valid = b < p.B;
+    if (!valid) b = p.B - 1;
+    f32x4 x = load_state<N>(p.x + b * N);
+    float Hval = 0.f;
+    f32x4 dx = M::template f<true>(lds, scr, ln, x, p.u[b], Hval);
+    if (valid && ln.q == 0) {
+      store_state<N>(p.dx + b * N, dx);
+      if (p.Hout) p.Hout[b] = Hval;
+    }
+  }
+}
+
+template <class M>
+__global__ __launch_bounds__(64 * kMaxWaves) void k_model_vjp(PointParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int N = M::N;
+  stage_image<M::IMG>(lds, p.img);
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  Lane ln;
+  ln.lane = threadIdx.x & 63;
+  ln.i = ln.lane & 15;
+  ln.q = ln.lane >> 4;
+  float* scr = lds + M::IMG + wave * kScrFloats;
+  const long long ntiles = (p.B + kTileB - 1) / kTileB;
+  for (long long tile = (long long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long long)gridDim.x * nwaves) {
+    long long b = tile * kTileB + ln.i;
+    const bool valid = b < p.B;
+    if (!valid) b = p.B - 1;
+    f32x4 x = load_state<N>(p.x + b * N);
+    f32x4 lam = load_state<N>(p.lam + b * N);
+    f32x4 xb;
+    float ub;
+    M::vjp(lds, scr, ln, x, p.u[b], lam, xb, ub);
+    if (valid && ln.q == 0) {
+      store_state<N>(p.dx + b * N, xb);
+      p.Hout[b] = ub;
+    }
+  }
+}
+
+// K3: Adam on the controls + best-iterate tracking (torch.optim.Adam single-tensor order)
+struct AdamParams {
+  float* u;
+  const float* g;
+  float* m;
+  float* v;
+  long long count, per;
+  float w1, w2, b2, bc2s, step_neg, eps;
+  const float* cost;
+  float* best_cost;
+  float* best_u;
+  float u_min, u_max;
+  int has_u_bounds;
+};
+
+__global__ void k_adam(AdamParams p) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.count) return;
+  float u = p.u[idx];
+  if (p.best_cost) {
+    long long b = idx / p.per;
+    // strict '<' against the value before this step's update (src/mpc_controller_canonical.py:212)
+    if (p.cost[b] < p.best_cost[b]) p.best_u[idx] = p.has_u_bounds ? fminf(fmaxf(u, p.u_min), p.u_max) : u;
+  }
+  float g = p.g[idx], m = p.m[idx], v = p.v[idx];
+  m = __builtin_fmaf(p.w1, g - m, m);
+  v = v * p.b2 + (p.w2 * g) * g;
+  float denom = sqrtf(v) / p.bc2s + p.eps;
+  u = u + (p.step_neg * m) / denom;
+  p.u[idx] = u;
+  p.m[idx] = m;
+  p.v[idx] = v;
+}
+
+// second pass of the best-iterate tracking: best_cost = min(best_cost, cost) (after k_adam used the old value)
+__global__ void k_best_cost(const float* cost, float* best_cost, long long B) {
+  long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B && cost[b] < best_cost[b]) best_cost[b] = cost[b];
+}

@@ -1,0 +1,560 @@
+// phnn_mpc.hip -- host side of the C-ABI declared in include/phnn_mpc.h: weight packing into the LDS
+// image the kernels stage, kernel selection and launches.  No CPU compute path exists here: every entry
+// point either launches a gfx950 kernel or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "phnn_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Variant {
+  V_NONE = 0,
+  V_PHNN_4_128_FIX,  // cart-pole pHNN (cartpole_mpc_config.yaml)
+  V_PHNN_4_64_FIX,
+  V_PHNN_2_64_GNET,  // pendulum pHNN with learned G (pendulum_config.yaml)
+  V_PHNN_2_64_FIX,
+  V_CANON_128,       // canonical cart-pole pHNN
+  V_CANON_64,
+  V_ODE_2_128,       // ODEFunc(2,1), hidden [128,128,128]
+  V_ODE_2_64,
+  V_ODE_3_128,
+};
+
+using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
+using M_PHNN_4_64_FIX = PhnnModel<4, 64, true>;
+using M_PHNN_2_64_GNET = PhnnModel<2, 64, false>;
+using M_PHNN_2_64_FIX = PhnnModel<2, 64, true>;
+using M_CANON_128 = CanonModel<128>;
+using M_CANON_64 = CanonModel<64>;
+using M_ODE_2_128 = OdeModel<2, 128>;
+using M_ODE_2_64 = OdeModel<2, 64>;
+using M_ODE_3_128 = OdeModel<3, 128>;
+
+struct KernelSet {
+  void (*fwd[2])(RollParams);
+  void (*grad[2])(RollParams);
+  void (*mfwd)(PointParams);
+  void (*mvjp)(PointParams);
+  int img_floats;
+  const char* name;
+};
+
+template <class M>
+KernelSet make_set(const char* name) {
+  KernelSet k;
+  k.fwd[0] = k_rollout_fwd<M, PHNN_INTEG_EULER>;
+  k.fwd[1] = k_rollout_fwd<M, PHNN_INTEG_RK4>;
+  k.grad[0] = k_rollout_grad<M, PHNN_INTEG_EULER>;
+  k.grad[1] = k_rollout_grad<M, PHNN_INTEG_RK4>;
+  k.mfwd = k_model_forward<M>;
+  k.mvjp = k_model_vjp<M>;
+  k.img_floats = M::IMG;
+  k.name = name;
+  return k;
+}
+
+bool kernel_set(int v, KernelSet* k) {
+  switch (v) {
+    case V_PHNN_4_128_FIX: *k = make_set<M_PHNN_4_128_FIX>("phnn<n=4,hid=128,fixedG>"); return true;
+    case V_PHNN_4_64_FIX: *k = make_set<M_PHNN_4_64_FIX>("phnn<n=4,hid=64,fixedG>"); return true;
+    case V_PHNN_2_64_GNET: *k = make_set<M_PHNN_2_64_GNET>("phnn<n=2,hid=64,Gnet>"); return true;
+    case V_PHNN_2_64_FIX: *k = make_set<M_PHNN_2_64_FIX>("phnn<n=2,hid=64,fixedG>"); return true;
+    case V_CANON_128: *k = make_set<M_CANON_128>("canonical<hid=128>"); return true;
+    case V_CANON_64: *k = make_set<M_CANON_64>("canonical<hid=64>"); return true;
+    case V_ODE_2_128: *k = make_set<M_ODE_2_128>("odefunc<n=2,hid=128>"); return true;
+    case V_ODE_2_64: *k = make_set<M_ODE_2_64>("odefunc<n=2,hid=64>"); return true;
+    case V_ODE_3_128: *k = make_set<M_ODE_3_128>("odefunc<n=3,hid=128>"); return true;
+    default: return false;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// description checks / blob walking (layout documented in include/phnn_mpc.h)
+// ---------------------------------------------------------------------------------------------
+size_t mlp_count(const phnn_mlp_shape& s, int in, int out) {
+  if (s.depth < 1 || s.depth > PHNN_MAX_LAYERS) return 0;
+  size_t c = 0;
+  int last = in;
+  for (int l = 0; l <= s.depth; ++l) {
+    int o = l < s.depth ? s.hidden[l] : out;
+    if (o < 1) return 0;
+    c += (size_t)o * last + o;
+    last = o;
+  }
+  return c;
+}
+
+size_t weight_count(const phnn_desc* d) {
+  if (!d || d->n < 1 || d->n > PHNN_MAX_N || d->m < 1 || d->m > PHNN_MAX_M) return 0;
+  int n = d->n, m = d->m;
+  if (d->kind == PHNN_MODEL_PHNN) {
+    size_t h = mlp_count(d->h_net, n, 1), r = mlp_count(d->r_net, n, n * n);
+    size_t g = d->fixed_G ? (size_t)n * m : mlp_count(d->g_net, n, n * m);
+    if (!h || !r || !g) return 0;
+    return (size_t)n * n + h + r + g;
+  }
+  if (d->kind == PHNN_MODEL_CANONICAL) {
+    size_t h = mlp_count(d->h_net, n, 1);
+    if (!h || n != 4) return 0;
+    return (size_t)n + (size_t)n * m + 3 + h;
+  }
+  if (d->kind == PHNN_MODEL_ODEFUNC) return mlp_count(d->h_net, n + m, n);
+  return 0;
+}
+
+bool same_hidden(const phnn_mlp_shape& s, int depth, int hid) {
+  if (s.depth != depth) return false;
+  for (int l = 0; l < depth; ++l)
+    if (s.hidden[l] != hid) return false;
+  return true;
+}
+
+int pick_variant(const phnn_desc* d, std::string* why) {
+  char buf[256];
+  if (d->m != 1) {
+    snprintf(buf, sizeof buf, "input_dim m=%d: the gfx950 kernels are instantiated for m=1 only", d->m);
+    *why = buf;
+    return V_NONE;
+  }
+  if (d->kind == PHNN_MODEL_PHNN) {
+    int hid = d->h_net.hidden[0];
+    bool ok = same_hidden(d->h_net, 2, hid) && same_hidden(d->r_net, 1, hid) &&
+              (d->fixed_G || same_hidden(d->g_net, 1, hid));
+    if (ok && d->n == 4 && hid == 128 && d->fixed_G) return V_PHNN_4_128_FIX;
+    if (ok && d->n == 4 && hid == 64 && d->fixed_G) return V_PHNN_4_64_FIX;
+    if (ok && d->n == 2 && hid == 64 && !d->fixed_G) return V_PHNN_2_64_GNET;
+    if (ok && d->n == 2 && hid == 64 && d->fixed_G) return V_PHNN_2_64_FIX;
+    snprintf(buf, sizeof buf,
+             "pHNN n=%d H_net depth %d width %d / R_net depth %d width %d fixed_G=%d: no kernel instantiated "
+             "(have n=4 hid 128|64 fixed G; n=2 hid 64 fixed or learned G; all nets one shared width)",
+             d->n, d->h_net.depth, hid, d->r_net.depth, d->r_net.hidden[0], d->fixed_G);
+    *why = buf;
+    return V_NONE;
+  }
+  if (d->kind == PHNN_MODEL_CANONICAL) {
+    int hid = d->h_net.hidden[0];
+    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 128) return V_CANON_128;
+    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 64) return V_CANON_64;
+    snprintf(buf, sizeof buf, "canonical pHNN n=%d H_net depth %d width %d: no kernel instantiated", d->n,
+             d->h_net.depth, hid);
+    *why = buf;
+    return V_NONE;
+  }
+  if (d->kind == PHNN_MODEL_ODEFUNC) {
+    int hid = d->h_net.hidden[0];
+    bool ok = same_hidden(d->h_net, 3, hid);
+    if (ok && d->n == 2 && hid == 128) return V_ODE_2_128;
+    if (ok && d->n == 2 && hid == 64) return V_ODE_2_64;
+    if (ok && d->n == 3 && hid == 128) return V_ODE_3_128;
+    snprintf(buf, sizeof buf, "ODEFunc n=%d depth %d width %d: no kernel instantiated (need n+m<=4, 3 hidden)",
+             d->n, d->h_net.depth, hid);
+    *why = buf;
+    return V_NONE;
+  }
+  *why = "unknown model kind";
+  return V_NONE;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS image packing
+// ---------------------------------------------------------------------------------------------
+template <int HID>
+void pack_in_frag(float* dst, const float* W, int nin) {  // W (HID, nin) -> [T][64]
+  for (int nt = 0; nt < HID / 16; ++nt)
+    for (int lane = 0; lane < 64; ++lane) {
+      int i = lane & 15, q = lane >> 4;
+      dst[nt * 64 + lane] = q < nin ? W[(size_t)(16 * nt + i) * nin + q] : 0.f;
+    }
+}
+template <int HID>
+void pack_in_frag_T(float* dst, const float* W, int nout) {  // W (nout, HID): frag of W^T (HID, nout)
+  for (int nt = 0; nt < HID / 16; ++nt)
+    for (int lane = 0; lane < 64; ++lane) {
+      int i = lane & 15, q = lane >> 4;
+      dst[nt * 64 + lane] = q < nout ? W[(size_t)q * HID + 16 * nt + i] : 0.f;
+    }
+}
+void pack_rows(float* dst, const float* W, int rows, int cols, int ld) {  // row-major (rows, cols) -> ld-padded
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) dst[(size_t)r * ld + c] = W[(size_t)r * cols + c];
+}
+void pack_cols_as_rows(float* dst, const float* W, int rows, int cols, int ld) {  // dst[c][r] = W[r][c]
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) dst[(size_t)c * ld + r] = W[(size_t)r * cols + c];
+}
+
+template <int HID>
+const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes W1,b1,W2,b2,W3,b3 from p
+  using Y = LayH2<HID>;
+  const float* W1 = p; p += (size_t)HID * nin;
+  const float* b1 = p; p += HID;
+  const float* W2 = p; p += (size_t)HID * HID;
+  const float* b2 = p; p += HID;
+  const float* W3 = p; p += HID;
+  const float* b3 = p; p += 1;
+  pack_rows(dst + Y::oW2, W2, HID, HID, Y::LD);
+  pack_in_frag<HID>(dst + Y::oW1f, W1, nin);
+  memcpy(dst + Y::oB1, b1, sizeof(float) * HID);
+  memcpy(dst + Y::oB2, b2, sizeof(float) * HID);
+  memcpy(dst + Y::oW3, W3, sizeof(float) * HID);
+  pack_cols_as_rows(dst + Y::oW1T, W1, HID, nin, Y::LR);
+  dst[Y::oB3] = b3[0];
+  return p;
+}
+
+template <int HID>
+const float* pack_h1(float* dst, const float* p, int nin, int nout) {  // R_net / G_net
+  using Y = LayH1<HID>;
+  const float* V1 = p; p += (size_t)HID * nin;
+  const float* c1 = p; p += HID;
+  const float* V2 = p; p += (size_t)nout * HID;
+  const float* c2 = p; p += nout;
+  pack_rows(dst + Y::oV2, V2, nout, HID, Y::LD);
+  pack_in_frag<HID>(dst + Y::oV1f, V1, nin);
+  memcpy(dst + Y::oC1, c1, sizeof(float) * HID);
+  memcpy(dst + Y::oC2, c2, sizeof(float) * nout);
+  pack_cols_as_rows(dst + Y::oV1T, V1, HID, nin, Y::LR);
+  return p;
+}
+
+template <class M>
+void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
+  constexpr int N = M::N, HID = M::HID;
+  img.assign(M::IMG, 0.f);
+  const float* J = p; p += N * N;
+  const float* G = nullptr;
+  if (d->fixed_G) { G = p; p += N; }
+  p = pack_h1<HID>(img.data() + M::oR, p, N, N * N);
+  p = pack_h2<HID>(img.data() + M::oH, p, N);
+  if (!d->fixed_G) p = pack_h1<HID>(img.data() + M::oGn, p, N, N);
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) img[M::oJ + i * N + j] = J[i * N + j] - J[j * N + i];  // src/pHNN.py:83, no 1/2
+  if (G)
+    for (int i = 0; i < N; ++i) img[M::oG + i] = G[i];
+}
+
+float softplus_host(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+template <class M>
+void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
+  constexpr int HID = M::HID;
+  img.assign(M::IMG, 0.f);
+  const float* Rd = p; p += 4;
+  const float* G = p; p += 4;
+  float log_a = p[0], b = p[1], log_c = p[2];
+  p += 3;
+  p = pack_h2<HID>(img.data() + M::oH, p, 4);
+  float* c = img.data() + M::oC;
+  c[0] = expf(log_a) + 1e-3f;  // src/mass_matrix.py:286-288
+  c[1] = b;
+  c[2] = expf(log_c) + 1e-3f;
+  for (int i = 0; i < 4; ++i) c[4 + i] = softplus_host(Rd[i]) + 1e-4f;  // src/pHNN_canonical.py:162
+  for (int i = 0; i < 4; ++i) c[8 + i] = G[i];
+}
+
+template <class M>
+void pack_ode(std::vector<float>& img, const phnn_desc* d, const float* p) {
+  constexpr int N = M::N, HID = M::HID;
+  const int nin = N + 1;
+  img.assign(M::IMG, 0.f);
+  const float* W1 = p; p += (size_t)HID * nin;
+  const float* b1 = p; p += HID;
+  const float* W2 = p; p += (size_t)HID * HID;
+  const float* b2 = p; p += HID;
+  const float* W3 = p; p += (size_t)HID * HID;
+  const float* b3 = p; p += HID;
+  const float* W4 = p; p += (size_t)N * HID;
+  const float* b4 = p; p += N;
+  pack_in_frag<HID>(img.data() + M::oW1f, W1, nin);
+  memcpy(img.data() + M::oB1, b1, sizeof(float) * HID);
+  pack_rows(img.data() + M::oW2, W2, HID, HID, M::LD);
+  memcpy(img.data() + M::oB2, b2, sizeof(float) * HID);
+  pack_rows(img.data() + M::oW3, W3, HID, HID, M::LD);
+  memcpy(img.data() + M::oB3, b3, sizeof(float) * HID);
+  pack_rows(img.data() + M::oW4r, W4, N, HID, M::LR);
+  memcpy(img.data() + M::oB4, b4, sizeof(float) * N);
+  pack_in_frag_T<HID>(img.data() + M::oW4f, W4, N);
+  pack_cols_as_rows(img.data() + M::oW1T, W1, HID, nin, M::LR);
+}
+
+void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float* blob) {
+  switch (v) {
+    case V_PHNN_4_128_FIX: pack_phnn<M_PHNN_4_128_FIX>(img, d, blob); break;
+    case V_PHNN_4_64_FIX: pack_phnn<M_PHNN_4_64_FIX>(img, d, blob); break;
+    case V_PHNN_2_64_GNET: pack_phnn<M_PHNN_2_64_GNET>(img, d, blob); break;
+    case V_PHNN_2_64_FIX: pack_phnn<M_PHNN_2_64_FIX>(img, d, blob); break;
+    case V_CANON_128: pack_canon<M_CANON_128>(img, d, blob); break;
+    case V_CANON_64: pack_canon<M_CANON_64>(img, d, blob); break;
+    case V_ODE_2_128: pack_ode<M_ODE_2_128>(img, d, blob); break;
+    case V_ODE_2_64: pack_ode<M_ODE_2_64>(img, d, blob); break;
+    case V_ODE_3_128: pack_ode<M_ODE_3_128>(img, d, blob); break;
+    default: break;
+  }
+}
+
+}  // namespace
+
+struct phnn_handle {
+  phnn_desc desc;
+  int device;
+  int variant;
+  KernelSet ks;
+  float* d_img;
+  int n_cu;
+  std::string err;
+};
+
+namespace {
+
+int fail(phnn_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+int hip_fail(phnn_handle* h, hipError_t e, const char* what) {
+  return fail(h, PHNN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// waves per workgroup: as many as 8 (2 per SIMD) once there are enough tiles to give every CU a
+// workgroup; fewer waves per workgroup for small batches so the tiles spread over the CUs.
+int pick_waves(long long tiles, int n_cu) {
+  int w = kMaxWaves;
+  while (w > 1 && (tiles + w - 1) / w < n_cu) w >>= 1;
+  return w;
+}
+
+template <class P>
+int launch(phnn_handle* h, void (*kern)(P), const P& p, long long tiles, bool grid_stride, hipStream_t st) {
+  int waves = pick_waves(tiles, h->n_cu);
+  long long grid = (tiles + waves - 1) / waves;
+  if (grid_stride && grid > 4LL * h->n_cu) grid = 4LL * h->n_cu;
+  if (grid < 1) grid = 1;
+  size_t shmem = sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * kScrFloats);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)shmem);
+  if (e != hipSuccess) return hip_fail(h, e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), shmem, st, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+  return PHNN_OK;
+}
+
+int check_device(phnn_handle* h) {
+  int cur = -1;
+  hipError_t e = hipGetDevice(&cur);
+  if (e != hipSuccess) return hip_fail(h, e, "hipGetDevice");
+  if (cur != h->device) {
+    e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
+  }
+  return PHNN_OK;
+}
+
+int check_cost(phnn_handle* h, const phnn_cost* c) {
+  if (!c) return fail(h, PHNN_ERR_INVALID_ARG, "cost is NULL");
+  if (c->has_u_bounds && !(c->u_min <= c->u_max)) return fail(h, PHNN_ERR_INVALID_ARG, "u_min > u_max");
+  return PHNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int phnn_version(void) { return 100; }
+
+size_t phnn_weight_count(const phnn_desc* desc) { return weight_count(desc); }
+
+const char* phnn_last_error(const phnn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_floats, int device, phnn_handle** out) {
+  if (!desc || !weights_host || !out) return fail(nullptr, PHNN_ERR_INVALID_ARG, "NULL argument");
+  *out = nullptr;
+  size_t need = weight_count(desc);
+  if (need == 0) return fail(nullptr, PHNN_ERR_INVALID_ARG, "invalid model description");
+  if (need != n_floats) {
+    char buf[128];
+    snprintf(buf, sizeof buf, "weight blob has %zu floats, description needs %zu", n_floats, need);
+    return fail(nullptr, PHNN_ERR_INVALID_ARG, buf);
+  }
+  std::string why;
+  int v = pick_variant(desc, &why);
+  if (v == V_NONE) return fail(nullptr, PHNN_ERR_UNSUPPORTED, why);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, PHNN_ERR_HIP, "no HIP device available (the rollout engine has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, PHNN_ERR_INVALID_ARG, "device index out of range");
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+  phnn_handle* h = new phnn_handle();
+  h->desc = *desc;
+  h->device = device;
+  h->variant = v;
+  kernel_set(v, &h->ks);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  h->n_cu = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  std::vector<float> img;
+  pack_image(v, img, desc, weights_host);
+  e = hipMalloc(reinterpret_cast<void**>(&h->d_img), sizeof(float) * img.size());
+  if (e != hipSuccess) {
+    delete h;
+    return hip_fail(nullptr, e, "hipMalloc(weights image)");
+  }
+  e = hipMemcpy(h->d_img, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    hipFree(h->d_img);
+    delete h;
+    return hip_fail(nullptr, e, "hipMemcpy(weights image)");
+  }
+  *out = h;
+  return PHNN_OK;
+}
+
+int phnn_destroy(phnn_handle* h) {
+  if (!h) return PHNN_OK;
+  if (h->d_img) hipFree(h->d_img);
+  delete h;
+  return PHNN_OK;
+}
+
+int phnn_model_forward(phnn_handle* h, const float* x_dev, const float* u_dev, int64_t B, float* dx_dev, float* H_dev,
+                       void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!x_dev || !u_dev || !dx_dev || B < 0) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
+  if (B == 0) return PHNN_OK;
+  if (int rc = check_device(h)) return rc;
+  PointParams p{h->d_img, x_dev, u_dev, nullptr, dx_dev, H_dev, (long long)B};
+  return launch(h, h->ks.mfwd, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
+}
+
+int phnn_model_vjp(phnn_handle* h, const float* x_dev, const float* u_dev, const float* lam_dev, int64_t B,
+                   float* xbar_dev, float* ubar_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!x_dev || !u_dev || !lam_dev || !xbar_dev || !ubar_dev || B < 0)
+    return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
+  if (B == 0) return PHNN_OK;
+  if (int rc = check_device(h)) return rc;
+  PointParams p{h->d_img, x_dev, u_dev, lam_dev, xbar_dev, ubar_dev, (long long)B};
+  return launch(h, h->ks.mvjp, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
+}
+
+static int fill_roll(phnn_handle* h, RollParams* p, const float* x0, const float* u, int64_t B, int32_t H,
+                     const phnn_cost* cost, int32_t integ, float dt) {
+  if (!x0 || !u || B < 0 || H < 1) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor, negative batch or horizon < 1");
+  if (integ != PHNN_INTEG_EULER && integ != PHNN_INTEG_RK4)
+    return fail(h, PHNN_ERR_INVALID_ARG, "Unknown integrator");  // src/integrators.py:172,226 raise ValueError
+  if (int rc = check_cost(h, cost)) return rc;
+  memset(p, 0, sizeof(*p));
+  p->img = h->d_img;
+  p->x0 = x0;
+  p->u = u;
+  p->B = B;
+  p->H = H;
+  // Python-float scalars of the reference: dt, dt/2, dt/6.0 formed in double, applied as float32
+  double dtd = (double)dt;
+  p->dt = dt;
+  p->half_dt = (float)(dtd / 2);
+  p->sixth_dt = (float)(dtd / 6.0);
+  p->c = *cost;
+  return PHNN_OK;
+}
+
+int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                     const phnn_cost* cost, int32_t integrator, float dt, float* cost_dev, float* traj_dev,
+                     void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  RollParams p;
+  if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
+  if (!cost_dev) return fail(h, PHNN_ERR_INVALID_ARG, "cost_dev is NULL");
+  if (B == 0) return PHNN_OK;
+  if (int rc = check_device(h)) return rc;
+  p.cost = cost_dev;
+  p.traj = traj_dev;
+  return launch(h, h->ks.fwd[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+}
+
+int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                      const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev, float* grad_u_dev,
+                      float* grad_x0_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  RollParams p;
+  if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
+  if (!traj_dev || !grad_u_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev / grad_u_dev is NULL");
+  if (B == 0) return PHNN_OK;
+  if (int rc = check_device(h)) return rc;
+  p.traj_in = traj_dev;
+  p.grad_u = grad_u_dev;
+  p.grad_x0 = grad_x0_dev;
+  return launch(h, h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+}
+
+int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
+                   int64_t count, float lr, float beta1, float beta2, float eps, int32_t step, const float* cost_dev,
+                   float* best_cost_dev, float* best_u_dev, int64_t per, float u_min, float u_max, int32_t has_u_bounds,
+                   void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!u_dev || !grad_dev || !exp_avg_dev || !exp_avg_sq_dev || count < 0 || step < 1)
+    return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor, negative count or step < 1");
+  if (best_cost_dev && (!cost_dev || !best_u_dev || per < 1 || count % per != 0))
+    return fail(h, PHNN_ERR_INVALID_ARG, "best-iterate tracking needs cost_dev, best_u_dev and per | count");
+  if (count == 0) return PHNN_OK;
+  if (int rc = check_device(h)) return rc;
+  AdamParams p;
+  memset(&p, 0, sizeof p);
+  p.u = u_dev;
+  p.g = grad_dev;
+  p.m = exp_avg_dev;
+  p.v = exp_avg_sq_dev;
+  p.count = count;
+  p.per = per > 0 ? per : 1;
+  // bias corrections are Python floats (double) in torch/optim/adam.py::_single_tensor_adam
+  double b1 = (double)beta1, b2 = (double)beta2;
+  double bc1 = 1.0 - std::pow(b1, (double)step), bc2 = 1.0 - std::pow(b2, (double)step);
+  p.w1 = (float)(1.0 - b1);
+  p.w2 = (float)(1.0 - b2);
+  p.b2 = beta2;
+  p.bc2s = (float)std::sqrt(bc2);
+  p.step_neg = (float)(-((double)lr / bc1));
+  p.eps = eps;
+  p.cost = cost_dev;
+  p.best_cost = best_cost_dev;
+  p.best_u = best_u_dev;
+  p.u_min = u_min;
+  p.u_max = u_max;
+  p.has_u_bounds = has_u_bounds;
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = 256;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((count + threads - 1) / threads)), dim3(threads), 0, st, p);
+  if (best_cost_dev) {
+    long long B = count / p.per;
+    hipLaunchKernelGGL(k_best_cost, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0, st, cost_dev,
+                       best_cost_dev, B);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "adam launch");
+  return PHNN_OK;
+}
+
+int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts_per_wg, int32_t* lds_bytes,
+                     int32_t* n_workgroups_for_B, int64_t B) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  (void)integrator;
+  long long tiles = (B + kTileB - 1) / kTileB;
+  int waves = pick_waves(tiles, h->n_cu);
+  if (rollouts_per_wg) *rollouts_per_wg = waves * kTileB;
+  if (lds_bytes) *lds_bytes = (int32_t)(sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * kScrFloats));
+  if (n_workgroups_for_B) *n_workgroups_for_B = (int32_t)((tiles + waves - 1) / waves);
+  return PHNN_OK;
+}
+
+}  // extern "C"

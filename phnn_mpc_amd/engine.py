@@ -1,0 +1,170 @@
+"""RolloutEngine: the thin Python face of the C-ABI (include/phnn_mpc.h) on torch device tensors.
+
+torch is plumbing here (device memory, streams); all arithmetic happens in the gfx950 kernels of
+csrc/libphnn_mpc.so.  There is no fallback: without the library or without a GPU, construction raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi, weights
+
+
+class PhnnError(RuntimeError):
+    pass
+
+
+def _check(lib, handle, rc):
+    if rc != 0:
+        msg = lib.phnn_last_error(handle)
+        msg = msg.decode() if msg else ""
+        if msg.startswith("Unknown integrator"):
+            raise ValueError(msg)  # the reference raises ValueError (src/integrators.py:172,226)
+        raise PhnnError(f"phnn_mpc error {rc}: {msg}")
+
+
+class RolloutEngine:
+    """One dynamics model resident on one GPU.
+
+    state_dict: the reference's state_dict (torch tensors or numpy arrays), or a checkpoint wrapping it.
+    """
+
+    def __init__(self, state_dict, device="cuda:0", kind=None):
+        self.lib = _capi.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise PhnnError("RolloutEngine needs a GPU device (cuda:N); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise PhnnError("no GPU visible to torch; the rollout engine has no CPU fallback")
+        self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind)
+        self.n, self.m, self.kind = self.desc.n, self.desc.m, self.desc.kind
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        h = C.c_void_p()
+        rc = self.lib.phnn_create(C.byref(self.desc), self.blob.ctypes.data_as(C.POINTER(C.c_float)), self.blob.size,
+                                  idx, C.byref(h))
+        _check(self.lib, None, rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.phnn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _t(self, a, shape=None):
+        t = torch.as_tensor(a, dtype=torch.float32, device=self.device)
+        if shape is not None:
+            t = t.reshape(shape)
+        return t.contiguous()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def _integ(self, integrator):
+        if isinstance(integrator, str):
+            if integrator not in _capi.INTEGRATORS:
+                raise ValueError(f"Unknown integrator: {integrator}")
+            return _capi.INTEGRATORS[integrator]
+        return int(integrator)
+
+    # ------------------------------------------------------------------ model(x,u), VJP
+    def forward(self, x, u):
+        x = self._t(x, (-1, self.n))
+        u = self._t(u, (-1, self.m))
+        B = x.shape[0]
+        dx = torch.empty_like(x)
+        H = torch.empty(B, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.h, self.lib.phnn_model_forward(self.h, self._p(x), self._p(u), B, self._p(dx), self._p(H),
+                                                             self._stream()))
+        return dx, H
+
+    def vjp(self, x, u, lam):
+        x = self._t(x, (-1, self.n))
+        u = self._t(u, (-1, self.m))
+        lam = self._t(lam, (-1, self.n))
+        B = x.shape[0]
+        xb = torch.empty_like(x)
+        ub = torch.empty(B, self.m, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.h, self.lib.phnn_model_vjp(self.h, self._p(x), self._p(u), self._p(lam), B, self._p(xb),
+                                                         self._p(ub), self._stream()))
+        return xb, ub
+
+    # ------------------------------------------------------------------ rollouts
+    def rollout_cost(self, x0, u, cost, integrator="euler", dt=0.02, want_traj=False, traj_out=None):
+        """K1.  x0 (B,n), u (B,H,m) -> cost (B) [, traj (B,H+1,n)]."""
+        x0 = self._t(x0, (-1, self.n))
+        B = x0.shape[0]
+        u = self._t(u).reshape(B, -1, self.m)
+        H = u.shape[1]
+        c = torch.empty(B, dtype=torch.float32, device=self.device)
+        traj = traj_out
+        if traj is None and want_traj:
+            traj = torch.empty(B, H + 1, self.n, dtype=torch.float32, device=self.device)
+        rc = self.lib.phnn_rollout_fwd(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), self._integ(integrator),
+                                       float(dt), self._p(c), self._p(traj), self._stream())
+        _check(self.lib, self.h, rc)
+        return (c, traj) if (want_traj or traj_out is not None) else c
+
+    def rollout_cost_grad(self, x0, u, cost, integrator="euler", dt=0.02, want_grad_x0=False, workspace=None):
+        """K1 + K2.  -> (cost (B), grad_u (B,H,m)[, grad_x0 (B,n)]).  `workspace`: optional dict reused across
+        calls to avoid re-allocating the trajectory / outputs."""
+        x0 = self._t(x0, (-1, self.n))
+        B = x0.shape[0]
+        u = self._t(u).reshape(B, -1, self.m)
+        H = u.shape[1]
+        ws = workspace if workspace is not None else {}
+        key = (B, H)
+        if ws.get("key") != key:
+            ws["key"] = key
+            ws["traj"] = torch.empty(B, H + 1, self.n, dtype=torch.float32, device=self.device)
+            ws["cost"] = torch.empty(B, dtype=torch.float32, device=self.device)
+            ws["grad_u"] = torch.empty(B, H, self.m, dtype=torch.float32, device=self.device)
+            ws["grad_x0"] = torch.empty(B, self.n, dtype=torch.float32, device=self.device)
+        integ = self._integ(integrator)
+        st = self._stream()
+        rc = self.lib.phnn_rollout_fwd(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), integ, float(dt),
+                                       self._p(ws["cost"]), self._p(ws["traj"]), st)
+        _check(self.lib, self.h, rc)
+        rc = self.lib.phnn_rollout_grad(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), integ, float(dt),
+                                        self._p(ws["traj"]), self._p(ws["grad_u"]),
+                                        self._p(ws["grad_x0"]) if want_grad_x0 else None, st)
+        _check(self.lib, self.h, rc)
+        if want_grad_x0:
+            return ws["cost"], ws["grad_u"], ws["grad_x0"]
+        return ws["cost"], ws["grad_u"]
+
+    # ------------------------------------------------------------------ Adam on the controls (K3)
+    def adam_step(self, u, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, cost=None,
+                  best_cost=None, best_u=None, u_min=None, u_max=None):
+        """In-place torch.optim.Adam step on u (B,H,m) (+ optional best-iterate tracking)."""
+        for t in (u, grad, exp_avg, exp_avg_sq):
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.device == self.device
+        per = u[0].numel() if u.dim() > 1 else 1
+        has_b = u_min is not None and u_max is not None
+        rc = self.lib.phnn_adam_step(self.h, self._p(u), self._p(grad), self._p(exp_avg), self._p(exp_avg_sq),
+                                     u.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                     self._p(cost), self._p(best_cost), self._p(best_u), per,
+                                     float(u_min) if has_b else 0.0, float(u_max) if has_b else 0.0, int(has_b),
+                                     self._stream())
+        _check(self.lib, self.h, rc)
+
+    def kernel_info(self, B, integrator="euler"):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.phnn_kernel_info(self.h, self._integ(integrator), C.byref(a), C.byref(b), C.byref(c), int(B))
+        return {"rollouts_per_workgroup": a.value, "lds_bytes": b.value, "workgroups": c.value}
+
+
+def as_numpy(t):
+    return t.detach().cpu().numpy().astype(np.float64)

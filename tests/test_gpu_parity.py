@@ -1,0 +1,180 @@
+"""GPU parity: the gfx950 kernels, called through the C-ABI, against (a) the float64 CPU oracle on the same
+seeded inputs and (b) the golden vectors the reference itself produced.
+
+Stated float32 tolerances (BASELINE.md section 3, 5-10x the reference's own f32-vs-f64 floor):
+  cost        rtol 1e-5
+  trajectory  atol 1e-5 + rtol 1e-5 for the cart-pole models; atol 5e-5 for the pendulum models, whose
+              trajectories swing to |x| ~ 11 and where the reference's OWN float32 run already differs from
+              its float64 run by 1.5e-5 (golden roll_euler_B2_H200: xH_f32 vs traj_f64)
+  grad_u      <= 1e-4 * max|grad| per rollout
+  f(x,u), VJP <= 2e-5 * max|.| over the batch
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(1, 20), (8, 50), (4, 100), (2, 200)]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module", params=ol.MODELS)
+def bundle(request, torch_cuda):
+    from phnn_mpc_amd.engine import RolloutEngine
+    name = request.param
+    w = ol.load_weights(name)
+    return name, ol.load_golden(name), ol.OracleModel(w, "f64"), RolloutEngine(w, "cuda:0")
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+TRAJ_ATOL = {"phnn_cartpole": 1e-5, "canonical_cartpole": 1e-5, "phnn_pendulum": 5e-5, "odefunc_pendulum": 5e-5}
+
+
+def assert_rollout_close(cost, traj, gu, gx0, ref_cost, ref_traj, ref_gu, ref_gx0, traj_atol=1e-5):
+    assert np.allclose(cost, ref_cost, rtol=1e-5, atol=0), np.abs(cost / ref_cost - 1).max()
+    if traj is not None:
+        assert np.allclose(traj, ref_traj, rtol=1e-5, atol=traj_atol), np.abs(traj - ref_traj).max()
+    gmax = np.abs(ref_gu).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(gu - ref_gu) <= 1e-4 * gmax), (np.abs(gu - ref_gu) / gmax).max()
+    if gx0 is not None:
+        xmax = np.abs(ref_gx0).max(axis=1, keepdims=True)
+        assert np.all(np.abs(gx0 - ref_gx0) <= 1e-4 * xmax), (np.abs(gx0 - ref_gx0) / xmax).max()
+
+
+def test_model_forward(bundle):
+    name, g, m64, eng = bundle
+    dx, H = eng.forward(g["fwd_x"], g["fwd_u"])
+    rdx, rH = m64.forward(g["fwd_x"], g["fwd_u"])
+    assert np.abs(npy(dx) - rdx).max() <= 2e-5 * np.abs(rdx).max()
+    assert np.abs(npy(H) - rH).max() <= 2e-5 * max(1.0, np.abs(rH).max())
+    # and against the reference's own outputs
+    assert np.abs(npy(dx) - g["fwd_dx_f64"]).max() <= 2e-5 * np.abs(rdx).max()
+
+
+def test_model_vjp(bundle):
+    name, g, m64, eng = bundle
+    xb, ub = eng.vjp(g["vjp_x"], g["vjp_u"], g["vjp_lam"])
+    assert np.abs(npy(xb) - g["vjp_xbar_f64"]).max() <= 2e-5 * np.abs(g["vjp_xbar_f64"]).max()
+    assert np.abs(npy(ub) - g["vjp_ubar_f64"]).max() <= 2e-5 * max(1e-30, np.abs(g["vjp_ubar_f64"]).max())
+
+
+def test_ragged_batches(bundle):
+    """Batch sizes that do not fill a 16-rollout wave tile or a workgroup (1, 15, 17, 130)."""
+    name, g, m64, eng = bundle
+    for B in (1, 15, 17, 130):
+        x, u = g["fwd_x"][:B], g["fwd_u"][:B]
+        dx, H = eng.forward(x, u)
+        rdx, rH = m64.forward(x, u)
+        assert dx.shape == (B, eng.n)
+        assert np.abs(npy(dx) - rdx).max() <= 2e-5 * np.abs(rdx).max()
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+@pytest.mark.parametrize("case", CASES)
+def test_rollout_vs_golden(bundle, integ, case):
+    name, g, m64, eng = bundle
+    B, H = case
+    key = f"roll_{integ}_B{B}_H{H}"
+    cost = ol.cost_from_golden(g)
+    c, gu, gx0 = eng.rollout_cost_grad(g[key + "_x0"], g[key + "_U"], cost, integ, float(g["dt"]), want_grad_x0=True)
+    c2, traj = eng.rollout_cost(g[key + "_x0"], g[key + "_U"], cost, integ, float(g["dt"]), want_traj=True)
+    assert np.array_equal(npy(c), npy(c2))
+    assert_rollout_close(npy(c), npy(traj), npy(gu), npy(gx0), g[key + "_cost_f64"], g[key + "_traj_f64"],
+                         g[key + "_gu_f64"], g[key + "_gx0_f64"], TRAJ_ATOL[name])
+    U = g[key + "_U"]
+    outside = (U > float(g["u_max"])) | (U < float(g["u_min"]))
+    assert np.all(npy(gu)[outside] == 0.0)
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_rollout_vs_oracle_seeded(bundle, integ):
+    """A larger seeded batch (B=300, ragged against 16 and 128) checked against the float64 oracle."""
+    name, g, m64, eng = bundle
+    rng = np.random.default_rng(4242)
+    n = eng.n
+    B, H = 300, 30
+    x0 = (rng.uniform(-1, 1, size=(B, n)) * np.array([1.0, 0.3, 0.5, 0.5][:n])).astype(np.float32)
+    amp = 1.3 * float(g["u_max"])
+    U = rng.uniform(-amp, amp, size=(B, H, 1)).astype(np.float32)
+    cost = ol.cost_from_golden(g)
+    ref = m64.rollout(x0, U, cost, integ, float(g["dt"]), nthreads=8)
+    c, gu, gx0 = eng.rollout_cost_grad(x0, U, cost, integ, float(g["dt"]), want_grad_x0=True)
+    _, traj = eng.rollout_cost(x0, U, cost, integ, float(g["dt"]), want_traj=True)
+    assert_rollout_close(npy(c), npy(traj), npy(gu), npy(gx0), ref["cost"], ref["traj"], ref["grad_u"], ref["grad_x0"],
+                         TRAJ_ATOL[name])
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_full_Q_target_and_barrier(torch_cuda, integ):
+    from phnn_mpc_amd import _capi
+    from phnn_mpc_amd.engine import RolloutEngine
+    g = ol.load_golden("phnn_cartpole")
+    w = ol.load_weights("phnn_cartpole")
+    eng, m64 = RolloutEngine(w), ol.OracleModel(w, "f64")
+    cost = ol.cost_from_golden(g, Q=g["fullq_Q"], x_target=g["fullq_xt"])
+    c, gu, gx0 = eng.rollout_cost_grad(g["fullq_x0"], g["fullq_U"], cost, integ, 0.02, want_grad_x0=True)
+    assert_rollout_close(npy(c), None, npy(gu), npy(gx0), g[f"fullq_{integ}_cost_f64"], None,
+                         g[f"fullq_{integ}_gu_f64"], g[f"fullq_{integ}_gx0_f64"])
+    # soft state barrier (src/mpc_controller.py:96-107) against the oracle
+    costb = _capi.make_cost(4, 1, g["Q"], g["R"], None, -15.0, 15.0, x_min=[-0.3, -0.1, -0.3, -0.2],
+                            x_max=[0.3, 0.1, 0.25, 0.15])
+    ref = m64.rollout(g["fullq_x0"], g["fullq_U"], costb, integ, 0.02)
+    c, gu, gx0 = eng.rollout_cost_grad(g["fullq_x0"], g["fullq_U"], costb, integ, 0.02, want_grad_x0=True)
+    assert_rollout_close(npy(c), None, npy(gu), npy(gx0), ref["cost"], None, ref["grad_u"], ref["grad_x0"])
+
+
+def test_dataset_windows(torch_cuda):
+    """Realistic magnitudes (G8): windows cut from the reference's own training data."""
+    from phnn_mpc_amd.engine import RolloutEngine
+    with np.load(ol.GOLDEN + "/golden_dataset_windows.npz") as z:
+        win = {k: z[k] for k in z.files}
+    gc = ol.load_golden("phnn_cartpole")
+    for nm, wn in (("phnn", "phnn_cartpole"), ("canonical", "canonical_cartpole")):
+        eng = RolloutEngine(ol.load_weights(wn))
+        c, gu = eng.rollout_cost_grad(win["x0"], win["U"], ol.cost_from_golden(gc), "euler", 0.02)
+        assert np.allclose(npy(c), win[f"{nm}_cost_f64"], rtol=2e-5)
+        gmax = np.abs(win[f"{nm}_gu_f64"]).max(axis=(1, 2), keepdims=True)
+        assert np.all(np.abs(npy(gu) - win[f"{nm}_gu_f64"]) <= 2e-4 * gmax)
+
+
+def test_repeatable_and_shard_equivalent(bundle):
+    """Bitwise run-to-run repeatability, and per-rollout results independent of how the batch is split
+    (what makes the multi-GPU sharding exact)."""
+    name, g, m64, eng = bundle
+    rng = np.random.default_rng(7)
+    B, H, n = 257, 25, eng.n
+    x0 = (rng.uniform(-1, 1, size=(B, n)) * 0.3).astype(np.float32)
+    U = rng.uniform(-1, 1, size=(B, H, 1)).astype(np.float32)
+    cost = ol.cost_from_golden(g)
+    c1, g1 = [npy(t).copy() for t in eng.rollout_cost_grad(x0, U, cost, "euler", float(g["dt"]))]
+    c2, g2 = [npy(t).copy() for t in eng.rollout_cost_grad(x0, U, cost, "euler", float(g["dt"]))]
+    assert np.array_equal(c1, c2) and np.array_equal(g1, g2)
+    ca, ga = [npy(t).copy() for t in eng.rollout_cost_grad(x0[:100], U[:100], cost, "euler", float(g["dt"]))]
+    cb, gb = [npy(t).copy() for t in eng.rollout_cost_grad(x0[100:], U[100:], cost, "euler", float(g["dt"]))]
+    assert np.array_equal(np.concatenate([ca, cb]), c1) and np.array_equal(np.concatenate([ga, gb]), g1)
+
+
+def test_errors(torch_cuda):
+    from phnn_mpc_amd.engine import PhnnError, RolloutEngine
+    w = ol.load_weights("phnn_cartpole")
+    eng = RolloutEngine(w)
+    g = ol.load_golden("phnn_cartpole")
+    with pytest.raises(ValueError):
+        eng.rollout_cost(g["fwd_x"][:4], np.zeros((4, 5, 1)), ol.cost_from_golden(g), "leapfrog", 0.02)
+    bad = dict(w)
+    bad["H_net.net.2.weight"] = np.zeros((96, 128), np.float32)
+    bad["H_net.net.2.bias"] = np.zeros(96, np.float32)
+    bad["H_net.net.4.weight"] = np.zeros((1, 96), np.float32)
+    with pytest.raises(PhnnError):
+        RolloutEngine(bad)
