@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement: pHNN-MPC rollouts+grads/sec, cart-pole pHNN, H=50, batch 65536 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch resident in HBM: K1 (fused forward march: clamp, pHNN
+dynamics, Euler step, stage cost over the whole horizon) then K2 (adjoint march -> d cost / d u), and, for
+N > 1, the one exchange the path has: an RCCL all-gather of the per-rollout costs.  Each rank works on its
+own 65536 rollouts (weak scaling; rollouts are independent).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      for the dominant kernel (K2, k_rollout_grad): algorithmic FLOPs per launch (SURVEY.md 8d:
+                74.2 kFLOP per rollout-step of VJP work; the in-kernel recompute of the forward tape is not
+                counted) / average launch duration measured live with events on the launch stream, against the
+                dense f32 MFMA peak of 157.3 TFLOP/s.  hbm_* fields give the same launch against the 8 TB/s HBM
+                roof from algorithmic bytes, as north_star asks -- the path is not HBM-bound.
+  cpu_baseline  the CPU oracle (plain-C port of the reference algorithm, float32, OpenMP over rollouts) timed
+                on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per rollout-step, cart-pole pHNN
+FLOP_FWD = 73.0e3  # f(x,u): H_net value+grad, R_net, combine
+FLOP_VJP = 72.7e3 + 1.5e3  # (df/dx)^T lam incl. Hessian-vector product
+PEAK_F32_MFMA = 157.3e12
+PEAK_HBM = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="rollouts per GPU")
+    ap.add_argument("--horizon", type=int, default=50)
+    ap.add_argument("--model", default="phnn_cartpole",
+                    choices=["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum"])
+    ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="rollouts timed on the host for cpu_baseline")
+    return ap.parse_args()
+
+
+def synthetic_inputs(n, B, H, rank, u_amp):
+    """x0 ranges of scripts/run_cartpole_mpc_enhanced.py:137-140, u ~ U(-5,5)."""
+    rng_x = np.random.default_rng(1234 + rank)
+    rng_u = np.random.default_rng(5678 + rank)
+    scale = np.array([1.0, 0.3, 0.5, 0.5][:n]) if n == 4 else np.array([np.pi, 1.0])
+    x0 = (rng_x.uniform(-1, 1, size=(B, n)) * scale).astype(np.float32)
+    U = rng_u.uniform(-u_amp, u_amp, size=(B, H, 1)).astype(np.float32)
+    return x0, U
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+
+    from phnn_mpc_amd import _capi
+    from phnn_mpc_amd.engine import RolloutEngine
+    gold = os.path.join(ROOT, "tests", "golden")
+    with np.load(os.path.join(gold, f"weights_{args.model}.npz")) as z:
+        w = {k: z[k] for k in z.files}
+    eng = RolloutEngine(w, dev)
+    n, B, H = eng.n, args.batch, args.horizon
+    cart = n == 4
+    dt = 0.02 if cart else 0.05
+    umax = 15.0 if cart else 2.0
+    cost = _capi.make_cost(n, 1, [10.0, 200.0, 1.0, 10.0] if cart else [10.0, 1.0], [0.01], None, -umax, umax)
+    x0_h, U_h = synthetic_inputs(n, B, H, rank, 5.0 if cart else 2.0)
+    x0 = torch.from_numpy(x0_h).to(dev)
+    U = torch.from_numpy(U_h).to(dev)
+    ws = {}
+    gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        c = eng.rollout_cost(x0, U, cost, args.integrator, dt, traj_out=ws_traj)[0]
+        if ev is not None:
+            ev[1].record()
+        eng.lib.phnn_rollout_grad(eng.h, eng._p(x0), eng._p(U), B, H, cost_ref, integ, float(dt), eng._p(ws_traj),
+                                  eng._p(ws_gu), None, eng._stream())
+        if ev is not None:
+            ev[2].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, c)
+        return c
+
+    import ctypes as C
+    cost_ref = C.byref(cost)
+    integ = _capi.INTEGRATORS[args.integrator]
+    ws_traj = torch.empty(B, H + 1, n, dtype=torch.float32, device=dev)
+    ws_gu = torch.empty(B, H, 1, dtype=torch.float32, device=dev)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        c_last = step(evs[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k1_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    k2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    assert torch.isfinite(c_last).all(), "non-finite cost in the bench workload"
+
+    if rank == 0:
+        stages = 4 if args.integrator == "rk4" else 1
+        value = world * B * args.steps / elapsed
+        flop_k2 = B * H * stages * FLOP_VJP  # algorithmic, per launch
+        flop_job = B * H * stages * (FLOP_FWD + FLOP_VJP)
+        bytes_k2 = B * (4 * (n + 2 * H) + 4)  # 4(n + 2 H m) + 4 per rollout with gradient
+        ach = flop_k2 / (k2_ms * 1e-3)
+        roof = {
+            "bound": "mfma", "kernel": "k_rollout_grad", "achieved": round(ach / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": None,
+            "launch_ms": round(k2_ms, 4), "k1_launch_ms": round(k1_ms, 4),
+            "job_tflops": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / 1e12, 3),
+            "job_frac": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / PEAK_F32_MFMA, 4),
+            "hbm_achieved_GBps": round(bytes_k2 / (k2_ms * 1e-3) / 1e9, 3),
+            "hbm_frac": round(bytes_k2 / (k2_ms * 1e-3) / PEAK_HBM, 6),
+        }
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(w, cost, x0_h, U_h, args.integrator, dt, args.cpu_sample)
+        out = {
+            "metric": "pHNN-MPC rollouts+grads/sec, cartpole H=50 batch=65536", "value": round(value, 1),
+            "unit": "rollouts+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} (seed-0 fixture weights) {args.integrator} H={H} "
+                                   f"B={B}/GPU: rollout + stage cost (K1) + control gradient (K2)"
+                                   + (" + RCCL all-gather of costs" if world > 1 else ""),
+                       "horizon": H, "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"shard{world}"},
+            "roofline": roof,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(w, cost, x0_h, U_h, integ, dt, sample):
+    """Time the float32 CPU oracle (test infrastructure, used here only as the measured baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    # the GPU box gives one GPU's job a 16-core share of the host whatever os.cpu_count() says
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
+    m = ol.OracleModel(w, "f32")
+    t = time.perf_counter()
+    m.rollout(x0_h[:256], U_h[:256], cost, integ, dt, traj=False, nthreads=cores)  # warm + pilot
+    pilot = 256 / max(time.perf_counter() - t, 1e-6)
+    S = int(min(max(sample, 12.0 * pilot), x0_h.shape[0]))  # aim at ~12 s of CPU work, bounded by the batch
+    t = time.perf_counter()
+    m.rollout(x0_h[:S], U_h[:S], cost, integ, dt, traj=False, nthreads=cores)
+    el = time.perf_counter() - t
+    return {"value": round(S / el, 1), "unit": "rollouts+grads/s", "cores": cores, "kind": "port",
+            "sample": f"first {S} rollouts of the same batch, float32 C oracle, OpenMP static over rollouts, {el:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()
