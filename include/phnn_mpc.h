@@ -131,6 +131,16 @@ int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, i
                       const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
                       float* grad_u_dev, float* grad_x0_dev, void* stream);
 
+/* General reverse pass of the rollout, what autograd does when a loss is built on BOTH outputs of
+ * rollout_trajectory_differentiable + compute_cost (src/integrators.py:192-258): given cotangents
+ * traj_bar_dev (B,H+1,n) on the trajectory (may be NULL = 0) and cost_bar_dev (B) on the cost (may be NULL = 1),
+ * returns grad_u_dev (B,H,m) and grad_x0_dev (B,n) (may be NULL).  phnn_rollout_grad is the special case
+ * traj_bar = 0, cost_bar = 1. */
+int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                     const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
+                     const float* traj_bar_dev, const float* cost_bar_dev, float* grad_u_dev, float* grad_x0_dev,
+                     void* stream);
+
 /* K3 -- Adam step on the controls, arithmetic order of torch.optim.Adam (single-tensor, defaults:
  * no weight decay / amsgrad) as used by src/mpc_controller.py:168,200 and
  * src/mpc_controller_canonical.py:186,206.  `step` is the 1-based step count after the increment.

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libphnn_mpc.so")
 # every symbol include/phnn_mpc.h declares
 EXPORTED = [
     "phnn_create", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
-    "phnn_model_vjp", "phnn_rollout_fwd", "phnn_rollout_grad", "phnn_adam_step", "phnn_kernel_info",
+    "phnn_model_vjp", "phnn_rollout_fwd", "phnn_rollout_grad", "phnn_rollout_vjp", "phnn_adam_step", "phnn_kernel_info",
     "phnn_version",
 ]
 
@@ -127,6 +127,9 @@ def load_library():
     lib.phnn_rollout_fwd.restype = C.c_int
     lib.phnn_rollout_grad.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, f32p, vp]
     lib.phnn_rollout_grad.restype = C.c_int
+    lib.phnn_rollout_vjp.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, f32p, f32p,
+                                     f32p, vp]
+    lib.phnn_rollout_vjp.restype = C.c_int
     lib.phnn_adam_step.argtypes = [vp, f32p, f32p, f32p, f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32,
                                    f32p, f32p, f32p, i64, C.c_float, C.c_float, i32, vp]
     lib.phnn_adam_step.restype = C.c_int

@@ -661,6 +661,8 @@ struct RollParams {
   const float* x0;     // (B,N)
   const float* u;      // (B,H)   (m = 1)
   const float* traj_in;  // (B,H+1,N)  K2
+  const float* traj_bar;  // (B,H+1,N) or null: cotangent on the trajectory (K2)
+  const float* cost_bar;  // (B) or null (= 1): cotangent on the cost (K2)
   float* cost;         // (B)
   float* traj;         // (B,H+1,N) or null
   float* grad_u;       // (B,H)
@@ -772,7 +774,10 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   const bool writer = valid && ln.q == 0;
   const float* tr = p.traj_in + (b * (p.H + 1)) * N;
   const float* up = p.u + b * p.H;
-  f32x4 lam = state_cost_grad<N>(p.c, load_state<N>(tr + (long long)p.H * N));
+  const float cb = p.cost_bar ? p.cost_bar[b] : 1.0f;
+  const float* tb = p.traj_bar ? p.traj_bar + (b * (p.H + 1)) * N : nullptr;
+  f32x4 lam = cb * state_cost_grad<N>(p.c, load_state<N>(tr + (long long)p.H * N));
+  if (tb) lam = lam + load_state<N>(tb + (long long)p.H * N);
   float Hd;
   for (int t = p.H - 1; t >= 0; --t) {
     f32x4 x = load_state<N>(tr + (long long)t * N);
@@ -802,8 +807,9 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
       utot += ub;
       lam = lam + yb1 + yb2 + yb3 + yb4;
     }
-    lam = lam + state_cost_grad<N>(p.c, x);
-    float g = __builtin_fmaf(2.0f * p.c.R[0], u, utot);
+    lam = lam + cb * state_cost_grad<N>(p.c, x);
+    if (tb) lam = lam + load_state<N>(tb + (long long)t * N);
+    float g = __builtin_fmaf(cb * (2.0f * p.c.R[0]), u, utot);
     if (p.c.has_u_bounds && !(uraw >= p.c.u_min && uraw <= p.c.u_max)) g = 0.f;
     if (writer) p.grad_u[b * p.H + t] = g;
   }

@@ -498,6 +498,24 @@ int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, i
   return launch(h, h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
 }
 
+int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                     const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
+                     const float* traj_bar_dev, const float* cost_bar_dev, float* grad_u_dev, float* grad_x0_dev,
+                     void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  RollParams p;
+  if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
+  if (!traj_dev || !grad_u_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev / grad_u_dev is NULL");
+  if (B == 0) return PHNN_OK;
+  if (int rc = check_device(h)) return rc;
+  p.traj_in = traj_dev;
+  p.traj_bar = traj_bar_dev;
+  p.cost_bar = cost_bar_dev;
+  p.grad_u = grad_u_dev;
+  p.grad_x0 = grad_x0_dev;
+  return launch(h, h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+}
+
 int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,
                    int64_t count, float lr, float beta1, float beta2, float eps, int32_t step, const float* cost_dev,
                    float* best_cost_dev, float* best_u_dev, int64_t per, float u_min, float u_max, int32_t has_u_bounds,

@@ -145,6 +145,23 @@ class RolloutEngine:
             return ws["cost"], ws["grad_u"], ws["grad_x0"]
         return ws["cost"], ws["grad_u"]
 
+    def rollout_vjp(self, x0, u, traj, cost, integrator="euler", dt=0.02, traj_bar=None, cost_bar=None):
+        """General reverse pass: cotangents on the trajectory (B,H+1,n) and/or the cost (B) -> (grad_u, grad_x0)."""
+        x0 = self._t(x0, (-1, self.n))
+        B = x0.shape[0]
+        u = self._t(u).reshape(B, -1, self.m)
+        H = u.shape[1]
+        traj = self._t(traj, (B, H + 1, self.n))
+        tb = self._t(traj_bar, (B, H + 1, self.n)) if traj_bar is not None else None
+        cb = self._t(cost_bar, (B,)) if cost_bar is not None else None
+        gu = torch.empty(B, H, self.m, dtype=torch.float32, device=self.device)
+        gx = torch.empty(B, self.n, dtype=torch.float32, device=self.device)
+        rc = self.lib.phnn_rollout_vjp(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), self._integ(integrator),
+                                       float(dt), self._p(traj), self._p(tb), self._p(cb), self._p(gu), self._p(gx),
+                                       self._stream())
+        _check(self.lib, self.h, rc)
+        return gu, gx
+
     # ------------------------------------------------------------------ Adam on the controls (K3)
     def adam_step(self, u, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, cost=None,
                   best_cost=None, best_u=None, u_min=None, u_max=None):

@@ -1,0 +1,114 @@
+"""Drop-in for src/integrators.py: same function names, arguments and return shapes.
+
+Single steps (euler_step, rk4_step, rk4_step_with_energy) compose model calls exactly as the reference does
+(each model call is one kernel launch).  The rollout functions send the whole horizon to the fused forward
+kernel K1 in ONE launch when the model is engine-backed, and rollout_trajectory_differentiable is
+differentiable w.r.t. y0 and controls through the adjoint kernel (phnn_rollout_vjp).
+"""
+import torch
+
+from . import _capi
+from .models import _EngineBacked, ODEFunc
+
+
+def _call(model, y, u):
+    if isinstance(model, ODEFunc):
+        return model.dynamics(y, u)
+    return model(y, u)
+
+
+def euler_step(model, y, u, dt):
+    """y_{t+1} = y_t + dt f(y_t,u_t)   (src/integrators.py:13-36)"""
+    return y + dt * _call(model, y, u)[0]
+
+
+def rk4_step(model, y, u, dt):
+    """classic RK4 with u held over the step (src/integrators.py:39-84)"""
+    k1 = _call(model, y, u)[0]
+    k2 = _call(model, y + (dt / 2) * k1, u)[0]
+    k3 = _call(model, y + (dt / 2) * k2, u)[0]
+    k4 = _call(model, y + dt * k3, u)[0]
+    return y + (dt / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+
+
+def rk4_step_with_energy(model, y, u, dt):
+    """RK4 step + H at the CURRENT state (stage k1), src/integrators.py:87-125"""
+    res = _call(model, y, u)
+    k1, H = res[0], res[1]
+    k2 = _call(model, y + (dt / 2) * k1, u)[0]
+    k3 = _call(model, y + (dt / 2) * k2, u)[0]
+    k4 = _call(model, y + dt * k3, u)[0]
+    return y + (dt / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4), H
+
+
+def _zero_cost(n, m):
+    import numpy as np
+    return _capi.make_cost(n, m, np.zeros((n, n)), np.zeros((m, m)))
+
+
+class _RolloutFn(torch.autograd.Function):
+    """trajectory = rollout(y0, controls) on K1; backward = general adjoint (traj cotangent) on K2."""
+
+    @staticmethod
+    def forward(ctx, y0, controls, model, dt, integrator):
+        eng = model.engine
+        y0d = y0.detach().to(eng.device, torch.float32).contiguous()
+        ud = controls.detach().to(eng.device, torch.float32).contiguous()
+        cost = _zero_cost(eng.n, eng.m)
+        _, traj = eng.rollout_cost(y0d, ud, cost, integrator, dt, want_traj=True)
+        ctx.model, ctx.dt, ctx.integ, ctx.cost = model, dt, integrator, cost
+        ctx.devs = (y0.device, controls.device)
+        ctx.save_for_backward(y0d, ud, traj)
+        return traj.to(y0.device)
+
+    @staticmethod
+    def backward(ctx, gtraj):
+        y0d, ud, traj = ctx.saved_tensors
+        eng = ctx.model.engine
+        zero = torch.zeros(y0d.shape[0], dtype=torch.float32, device=eng.device)
+        gu, gx = eng.rollout_vjp(y0d, ud, traj, ctx.cost, ctx.integ, ctx.dt,
+                                 traj_bar=gtraj.to(eng.device, torch.float32).contiguous(), cost_bar=zero)
+        return gx.to(ctx.devs[0]), gu.to(ctx.devs[1]), None, None, None
+
+
+def _check_integrator(integrator):
+    if integrator not in ("rk4", "euler"):
+        raise ValueError(f"Unknown integrator: {integrator}")
+
+
+def _energies(model, traj, controls):
+    """H along a trajectory with the reference's indexing quirks handled by the callers."""
+    B, T1, n = traj.shape
+    m = controls.shape[-1]
+    u_pad = torch.cat([controls, controls[:, -1:]], dim=1)  # u used only as a formal argument of model(y,u)
+    H = _call(model, traj.reshape(B * T1, n), u_pad.reshape(B * T1, m))[1]
+    return H.reshape(B, T1)
+
+
+def rollout_trajectory(model, y0, controls, dt, integrator="rk4"):
+    """-> trajectory (B,T+1,n), energies (B,T+1)   (src/integrators.py:128-189; H at every stored state)."""
+    _check_integrator(integrator)
+    if not isinstance(model, _EngineBacked):
+        raise TypeError("rollout_trajectory needs an engine-backed model (phnn_mpc_amd.models)")
+    with torch.no_grad():
+        traj = _RolloutFn.apply(y0, controls, model, dt, integrator)
+        energies = _energies(model, traj, controls)
+    return traj, energies
+
+
+def rollout_trajectory_differentiable(model, y0, controls, dt, integrator="rk4", return_energies=False):
+    """-> trajectory (B,T+1,n) [, energies (B,T+1)]   (src/integrators.py:192-258).
+
+    Differentiable w.r.t. y0 and controls.  With return_energies the reference returns H at the CURRENT state of
+    each step, so energies[:,1] duplicates energies[:,0]; reproduced here.
+    """
+    _check_integrator(integrator)
+    if not isinstance(model, _EngineBacked):
+        raise TypeError("rollout_trajectory_differentiable needs an engine-backed model (phnn_mpc_amd.models)")
+    traj = _RolloutFn.apply(y0, controls, model, dt, integrator)
+    if not return_energies:
+        return traj
+    with torch.no_grad():
+        Hall = _energies(model, traj, controls)
+    energies = torch.cat([Hall[:, :1], Hall[:, :-1]], dim=1)
+    return traj, energies

@@ -1,0 +1,268 @@
+"""Drop-in model classes: same constructor arguments, state_dict keys and call signatures as the reference's
+nn.Modules, with forward() served by the gfx950 kernels through RolloutEngine.
+
+  pHNN            <- src/pHNN.py:12-100            model(x,u) -> (dx, H)
+  pHNN_Canonical  <- src/pHNN_canonical.py:40-290  model(y,u) -> (dy, H, None)
+  ODEFunc         <- src/baseline_node.py:19-116   f(t, state) with the current_action attribute
+
+The modules only hold parameters (so checkpoints of the reference load with load_state_dict) and hand a
+packed copy of them to the engine; no dynamics arithmetic is done in torch.  Unlike the reference, the
+input does not need requires_grad and the call works under torch.no_grad() (SURVEY.md quirk 6 is an
+artefact of autograd.grad inside forward).  First-order gradients w.r.t. x and u flow through the returned
+dx (custom autograd.Function backed by phnn_model_vjp); H is returned without a graph.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import yaml
+
+from . import _capi
+
+DEFAULT_DEVICE = "cuda:0"
+
+
+def _activation(name):
+    return getattr(nn, name.split(".")[-1])  # same resolution rule as src/pHNN.py:41
+
+
+class MLP(nn.Module):
+    """Parameter container with the reference's layout: self.net = Sequential(Linear, act, ..., Linear)
+    (src/NN.py:6-40), so state_dict keys read '<name>.net.<2k>.weight'."""
+
+    def __init__(self, input_dim, output_dim, hidden_sizes=(128, 128), activation=nn.SiLU, dropout=0.0,
+                 layer_norm=False, bias=True):
+        super().__init__()
+        self.activation_name = activation.__name__
+        self.plain = (not layer_norm) and dropout == 0 and bias
+        mods, last = [], input_dim
+        for h in hidden_sizes:
+            mods.append(nn.Linear(last, h, bias=bias))
+            if layer_norm:
+                mods.append(nn.LayerNorm(h))
+            mods.append(activation())
+            if dropout > 0:
+                mods.append(nn.Dropout(dropout))
+            last = h
+        mods.append(nn.Linear(last, output_dim, bias=bias))
+        self.net = nn.Sequential(*mods)
+        for m in self.net:  # Kaiming-uniform(a=sqrt 5) weights, U(+-1/sqrt(fan_in)) biases
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
+                if m.bias is not None:
+                    bound = 1 / math.sqrt(m.in_features) if m.in_features > 0 else 0.0
+                    nn.init.uniform_(m.bias, -bound, bound)
+
+
+def _mlp_from(params, input_dim, output_dim):
+    return MLP(input_dim, output_dim, hidden_sizes=tuple(params["hidden_sizes"]), activation=_activation(params["activation"]),
+               dropout=params["dropout"], layer_norm=params["layer_norm"], bias=params["bias"])
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, u, owner):
+        eng = owner.engine
+        xd, ud = x.detach().to(eng.device, torch.float32), u.detach().to(eng.device, torch.float32)
+        dx, H = eng.forward(xd, ud)
+        ctx.owner, ctx.dev = owner, x.device
+        ctx.save_for_backward(xd, ud)
+        ctx.mark_non_differentiable(H)
+        return dx.to(x.device), H.to(x.device)
+
+    @staticmethod
+    def backward(ctx, gdx, gH):
+        xd, ud = ctx.saved_tensors
+        eng = ctx.owner.engine
+        xb, ub = eng.vjp(xd, ud, gdx.to(eng.device, torch.float32))
+        return xb.to(ctx.dev), ub.to(ctx.dev), None
+
+
+class _EngineBacked(nn.Module):
+    """Shared plumbing: lazily built engine, invalidated when parameters are (re)loaded."""
+
+    def __init__(self):
+        super().__init__()
+        self._engine = None
+        self._engine_device = DEFAULT_DEVICE
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._check_supported()
+            from .engine import RolloutEngine
+            self._engine = RolloutEngine(self.state_dict(), self._engine_device)
+        return self._engine
+
+    def set_engine(self, engine):
+        """Attach an already built engine (tests use this to run the host logic without a GPU)."""
+        self._engine = engine
+        return self
+
+    def refresh_engine(self):
+        """Call after changing parameters in place; the next call re-packs and re-uploads them."""
+        if self._engine is not None and hasattr(self._engine, "close"):
+            self._engine.close()
+        self._engine = None
+
+    def use_device(self, device):
+        self._engine_device = str(device)
+        self.refresh_engine()
+        return self
+
+    def load_state_dict(self, state_dict, *a, **k):
+        r = super().load_state_dict(state_dict, *a, **k)
+        self.refresh_engine()
+        return r
+
+    def _check_supported(self):
+        for name, mod in self.named_modules():
+            if isinstance(mod, MLP) and (not mod.plain or mod.activation_name != "Tanh"):
+                raise NotImplementedError(
+                    f"{name}: the rollout kernels implement Linear/Tanh MLPs (bias, no LayerNorm/Dropout), the only "
+                    f"variant the shipped configs select; got activation={mod.activation_name}, plain={mod.plain}")
+
+    @staticmethod
+    def _flatten(x):  # src/pHNN.py:58-66
+        if x.ndim == 1:
+            return x.unsqueeze(0)
+        if x.ndim > 2:
+            return x.reshape(-1, x.shape[-1])
+        return x
+
+
+class pHNN(_EngineBacked):
+    def __init__(self, config_path: str):
+        super().__init__()
+        with open(config_path, "r") as f:
+            config = yaml.safe_load(f)
+        mc = config["model"]
+        n, m = mc["state_dim"], mc["input_dim"]
+        self.J = nn.Parameter(torch.randn(n, n))
+        self.R_net = _mlp_from(mc["R_mlp"], n, n * n)
+        self.H_net = _mlp_from(mc["H_mlp"], n, 1)
+        if mc.get("fixed_G", False):
+            self.register_buffer("G_fixed", torch.tensor(mc["G_value"], dtype=torch.float32))
+            self.G_net = None
+        else:
+            self.G_net = _mlp_from(mc["G_mlp"], n, m * n)
+
+    def forward(self, x, u):
+        x, u = self._flatten(x), self._flatten(u)
+        return _ModelFn.apply(x, u, self)
+
+
+class CartPoleMassMatrix(nn.Module):
+    """Parameters of M(theta) = [[a, b cos], [b cos, c]] (src/mass_matrix.py:239-370).  forward/inverse are the
+    small closed forms, kept for the reference's diagnostic helpers; the hot path evaluates them in-kernel."""
+
+    def __init__(self, init_a=1.0, init_b=0.1, init_c=1.0):
+        super().__init__()
+        self.log_a = nn.Parameter(torch.log(torch.tensor(init_a)))
+        self.b = nn.Parameter(torch.tensor(init_b))
+        self.log_c = nn.Parameter(torch.log(torch.tensor(init_c)))
+
+    def _abc(self):
+        return (torch.exp(self.log_a) + 1e-3).item(), self.b.item(), (torch.exp(self.log_c) + 1e-3).item()
+
+    def forward(self, q):
+        a, b, c = self._abc()
+        bc = b * torch.cos(q[:, 1])
+        M = torch.zeros(q.shape[0], 2, 2, dtype=q.dtype, device=q.device)
+        M[:, 0, 0], M[:, 1, 1] = a, c
+        M[:, 0, 1] = M[:, 1, 0] = bc
+        return M
+
+    def inverse(self, q):
+        a, b, c = self._abc()
+        bc = b * torch.cos(q[:, 1])
+        det = a * c - bc ** 2 + 1e-6
+        Mi = torch.zeros(q.shape[0], 2, 2, dtype=q.dtype, device=q.device)
+        Mi[:, 0, 0], Mi[:, 1, 1] = c / det, a / det
+        Mi[:, 0, 1] = Mi[:, 1, 0] = -bc / det
+        return Mi
+
+    def get_parameters_dict(self):
+        a, b, c = self._abc()
+        return {"a": a, "b": b, "c": c}
+
+
+class pHNN_Canonical(_EngineBacked):
+    def __init__(self, config_path: str):
+        super().__init__()
+        with open(config_path, "r") as f:
+            config = yaml.safe_load(f)
+        mc = config["model"]
+        self.state_dim, self.input_dim = mc["state_dim"], mc["input_dim"]
+        self.q_dim = self.state_dim // 2
+        mass = mc.get("mass_matrix", {})
+        if mass.get("type", "cartpole") != "cartpole":
+            raise NotImplementedError("only mass_matrix.type == 'cartpole' (the shipped config) has a kernel; "
+                                      "MassMatrixNetwork variants are out of scope (SURVEY.md 2.1 #4)")
+        self.M_net = CartPoleMassMatrix(mass.get("init_a", 1.0), mass.get("init_b", 0.1), mass.get("init_c", 1.0))
+        self.H_net = _mlp_from(mc["H_mlp"], self.state_dim, 1)
+        J = torch.zeros(self.state_dim, self.state_dim)
+        J[:self.q_dim, self.q_dim:] = torch.eye(self.q_dim)
+        J[self.q_dim:, :self.q_dim] = -torch.eye(self.q_dim)
+        self.register_buffer("J", J)
+        self.R_diag_raw = nn.Parameter(torch.ones(self.state_dim) * 0.1)
+        if not mc.get("fixed_G", False):
+            raise ValueError("pHNN_Canonical requires fixed_G=True")
+        self.register_buffer("G", torch.tensor(mc["G_value"], dtype=torch.float32))
+
+    def get_R_matrix(self, batch_size):
+        R = torch.diag(torch.nn.functional.softplus(self.R_diag_raw) + 1e-4)
+        return R.unsqueeze(0).expand(batch_size, -1, -1)
+
+    def forward(self, y, u, return_intermediate=False):
+        if return_intermediate:
+            raise NotImplementedError("return_intermediate=True (diagnostic dict) is not produced by the fused kernel")
+        y, u = self._flatten(y), self._flatten(u)
+        dy, H = _ModelFn.apply(y, u, self)
+        return dy, H, None
+
+    def get_velocity_reconstruction(self, y):
+        q, qd = y[:, :self.q_dim], y[:, self.q_dim:]
+        p = torch.bmm(self.M_net(q), qd.unsqueeze(-1))
+        return torch.bmm(self.M_net.inverse(q), p).squeeze(-1)
+
+
+class ODEFunc(_EngineBacked):
+    def __init__(self, state_dim=4, action_dim=1, hidden_sizes=[128, 128, 128], activation="tanh", layer_norm=False):
+        super().__init__()
+        self.state_dim, self.action_dim = state_dim, action_dim
+        self.current_action = None
+        acts = {"relu": nn.ReLU, "tanh": nn.Tanh, "elu": nn.ELU, "gelu": nn.GELU}
+        if activation not in acts:
+            raise ValueError(f"Unknown activation: {activation}")
+        self._plain = activation == "tanh" and not layer_norm
+        mods, prev = [], state_dim + action_dim
+        for h in hidden_sizes:
+            mods.append(nn.Linear(prev, h))
+            if layer_norm:
+                mods.append(nn.LayerNorm(h))
+            mods.append(acts[activation]())
+            prev = h
+        mods.append(nn.Linear(prev, state_dim))
+        self.network = nn.Sequential(*mods)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def _check_supported(self):
+        if not self._plain:
+            raise NotImplementedError("the ODEFunc kernel implements tanh without LayerNorm (the default)")
+
+    def forward(self, t, state):
+        if self.current_action is None:
+            raise RuntimeError("current_action must be set before calling forward")
+        action = self.current_action
+        if action.shape[0] == 1 and state.shape[0] > 1:
+            action = action.expand(state.shape[0], -1)
+        dx, _ = _ModelFn.apply(state, action, self)
+        return dx
+
+    def dynamics(self, y, u):
+        """model(y,u) -> (dy, H=0) view used by the integrators (no side channel)."""
+        return _ModelFn.apply(self._flatten(y), self._flatten(u), self)

@@ -137,6 +137,25 @@ def model_block(name, model, n, m, dt, Q, R, xt, umin, umax, xlo, xhi, uamp, see
                 out[f"{key}_cost_{tag}"] = cost
                 out[f"{key}_gu_{tag}"] = gu
                 out[f"{key}_gx0_{tag}"] = gx
+    # ---- G10: reverse pass with a random cotangent on the trajectory and on the cost
+    B, H = 4, 30
+    x0 = rng.uniform(xlo, xhi, size=(B, n)).astype(np.float32)
+    U = rng.uniform(-uamp, uamp, size=(B, H, m)).astype(np.float32)
+    U[1, 2, 0] = np.float32(umax * 1.5)
+    Wt = rng.normal(size=(B, H + 1, n)).astype(np.float32)
+    wc = rng.normal(size=(B,)).astype(np.float32)
+    out["tvjp_x0"], out["tvjp_U"], out["tvjp_traj_bar"], out["tvjp_cost_bar"] = x0, U, Wt, wc
+    for integ in ("euler", "rk4"):
+        mm = copy.deepcopy(model).double()
+        y0 = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
+        Ur = torch.tensor(U, dtype=torch.float64, requires_grad=True)
+        Uc = torch.clamp(Ur, umin, umax)
+        traj = integrators.rollout_trajectory_differentiable(mm, y0, Uc, dt, integ)
+        f32 = lambda a: torch.tensor(np.asarray(a, np.float32)).double()
+        cost = batched_cost(traj, Uc, f32(Q), f32(R), f32(xt))
+        loss = (traj * torch.tensor(Wt, dtype=torch.float64)).sum() + (cost * torch.tensor(wc, dtype=torch.float64)).sum()
+        gu, gx = torch.autograd.grad(loss, [Ur, y0])
+        out[f"tvjp_{integ}_gu_f64"], out[f"tvjp_{integ}_gx0_f64"] = gu.numpy(), gx.numpy()
     return out
 
 

@@ -1,0 +1,53 @@
+"""OracleEngine: the engine protocol (what controllers / solver / distributed code call) served by the CPU
+oracle on CPU tensors.  TEST INFRASTRUCTURE: lets the host logic be exercised without a GPU.  The product's
+engine is phnn_mpc_amd.engine.RolloutEngine; nothing in the package imports this file.
+"""
+import numpy as np
+import torch
+
+import oracle_lib as ol
+from phnn_mpc_amd import _capi
+
+
+class OracleEngine:
+    def __init__(self, state_dict, precision="f32"):
+        self.m_ = ol.OracleModel(state_dict, precision)
+        self.n, self.m = self.m_.n, self.m_.m
+        self.device = torch.device("cpu")
+        self.np_dtype = self.m_.dtype
+
+    def _out(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+
+    def forward(self, x, u):
+        dx, H = self.m_.forward(x.numpy(), u.numpy())
+        return self._out(dx), self._out(H)
+
+    def vjp(self, x, u, lam):
+        xb, ub = self.m_.vjp(x.numpy(), u.numpy(), lam.numpy())
+        return self._out(xb), self._out(ub)
+
+    def rollout_cost(self, x0, u, cost, integrator="euler", dt=0.02, want_traj=False, traj_out=None):
+        r = self.m_.rollout(np.asarray(x0), np.asarray(u), cost, integrator, dt, grad=False, traj=True)
+        c, t = self._out(r["cost"]), self._out(r["traj"])
+        return (c, t) if want_traj else c
+
+    def rollout_cost_grad(self, x0, u, cost, integrator="euler", dt=0.02, want_grad_x0=False, workspace=None):
+        r = self.m_.rollout(np.asarray(x0), np.asarray(u), cost, integrator, dt, grad=True, traj=False)
+        out = (self._out(r["cost"]), self._out(r["grad_u"]))
+        return out + (self._out(r["grad_x0"]),) if want_grad_x0 else out
+
+    def adam_step(self, u, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, cost=None,
+                  best_cost=None, best_u=None, u_min=None, u_max=None):
+        if best_cost is not None:
+            better = cost < best_cost
+            uc = torch.clamp(u, u_min, u_max) if (u_min is not None and u_max is not None) else u
+            best_u[better] = uc[better]
+            best_cost[better] = cost[better]
+        f32 = ol.OracleModel  # noqa: F841  (Adam restatement lives in the f32 oracle build)
+        lib = ol.lib()
+        import ctypes as C
+        for t in (u, grad, exp_avg, exp_avg_sq):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        lib.oracle_adam_f32(C.c_void_p(u.data_ptr()), C.c_void_p(grad.data_ptr()), C.c_void_p(exp_avg.data_ptr()),
+                            C.c_void_p(exp_avg_sq.data_ptr()), u.numel(), lr, beta1, beta2, eps, step)

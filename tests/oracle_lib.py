@@ -33,6 +33,9 @@ def lib():
             getattr(_lib, f"oracle_rollout_{suf}").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
                                                                C.POINTER(_capi.Cost), C.c_int, C.c_double,
                                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            getattr(_lib, f"oracle_rollout_vjp_{suf}").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
+                                                                   C.POINTER(_capi.Cost), C.c_int, C.c_double,
+                                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
             getattr(_lib, f"oracle_adam_{suf}").argtypes = [C.c_void_p] * 4 + [C.c_long] + [C.c_double] * 4 + [C.c_int]
     return _lib
 
@@ -89,6 +92,19 @@ class OracleModel:
         getattr(lib(), f"oracle_rollout_{self.suf}")(self.h, _ptr(x0), _ptr(U), B, H, C.byref(cost), integ, float(dt),
                                                      _ptr(c), _ptr(tr), _ptr(gu), _ptr(gx), int(nthreads))
         return {"cost": c, "traj": tr, "grad_u": gu, "grad_x0": gx}
+
+    def rollout_vjp(self, x0, U, cost, integrator, dt, traj_bar=None, cost_bar=None):
+        x0 = self._a(x0, (-1, self.n))
+        B = x0.shape[0]
+        U = self._a(U).reshape(B, -1, self.m)
+        H = U.shape[1]
+        tb = None if traj_bar is None else self._a(traj_bar, (B, H + 1, self.n))
+        cb = None if cost_bar is None else self._a(cost_bar, (B,))
+        gu, gx = np.empty((B, H, self.m), self.dtype), np.empty((B, self.n), self.dtype)
+        integ = _capi.INTEGRATORS[integrator] if isinstance(integrator, str) else int(integrator)
+        getattr(lib(), f"oracle_rollout_vjp_{self.suf}")(self.h, _ptr(x0), _ptr(U), B, H, C.byref(cost), integ,
+                                                         float(dt), _ptr(tb), _ptr(cb), _ptr(gu), _ptr(gx))
+        return gu, gx
 
     def adam(self, p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
         """In-place Adam step on arrays of self.dtype."""

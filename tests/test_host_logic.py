@@ -1,0 +1,238 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the weight packer, the model
+classes' state_dict layout, and the controller host logic -- driven by the CPU oracle through the engine
+protocol (tests/oracle_engine.py) and pinned to the reference's own controller outputs (golden sets G5, G6, G9).
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import oracle_lib as ol
+from oracle_engine import OracleEngine
+from phnn_mpc_amd import _capi, weights
+from phnn_mpc_amd.models import ODEFunc, pHNN, pHNN_Canonical
+from phnn_mpc_amd.mpc_controller import MPCController, create_mpc_from_config
+from phnn_mpc_amd.mpc_controller_canonical import MPCControllerCanonical, create_mpc_controller
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs", "cartpole_mpc.yaml")
+CFG_PEND = os.path.join(ROOT, "configs", "pendulum.yaml")
+
+
+@pytest.fixture(scope="module")
+def ctl():
+    with np.load(os.path.join(ol.GOLDEN, "golden_controllers.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+# ----------------------------------------------------------------------------- C-ABI surface
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load_library()
+    header = open(os.path.join(ROOT, "include", "phnn_mpc.h")).read()
+    declared = set(re.findall(r"\b(phnn_[a-z_]+)\s*\(", header))
+    assert declared == set(_capi.EXPORTED), declared ^ set(_capi.EXPORTED)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.phnn_version() >= 100
+
+
+def test_struct_sizes_match_header():
+    # phnn_desc: 4 ints + 3 * (1 + 4) ints ; phnn_cost: 64+16+8 floats, 2 floats, int, 16 floats, 2 ints, float
+    assert C.sizeof(_capi.Desc) == 4 * (4 + 3 * 5)
+    assert C.sizeof(_capi.Cost) == 4 * (64 + 16 + 8 + 2 + 1 + 16 + 2 + 1)
+
+
+@pytest.mark.parametrize("name", ol.MODELS)
+def test_weight_count_and_packer(name):
+    lib = _capi.load_library()
+    d, blob = weights.pack_state_dict(ol.load_weights(name))
+    assert lib.phnn_weight_count(C.byref(d)) == blob.size
+    assert blob.dtype == np.float32 and blob.flags.c_contiguous
+
+
+def test_create_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _capi.load_library()
+    d, blob = weights.pack_state_dict(ol.load_weights("phnn_cartpole"))
+    h = C.c_void_p()
+    rc = lib.phnn_create(C.byref(d), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, 0, C.byref(h))
+    assert rc < 0 and not h.value
+    assert b"no HIP device" in lib.phnn_last_error(None) or b"hip" in lib.phnn_last_error(None).lower()
+    from phnn_mpc_amd.engine import PhnnError, RolloutEngine
+    with pytest.raises(PhnnError):
+        RolloutEngine(ol.load_weights("phnn_cartpole"))
+
+
+def test_unsupported_descriptions_are_refused():
+    lib = _capi.load_library()
+    w = ol.load_weights("phnn_cartpole")
+    d, blob = weights.pack_state_dict(w)
+    h = C.c_void_p()
+    assert lib.phnn_create(C.byref(d), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size - 1, 0, C.byref(h)) == -1
+    d.h_net.hidden[1] = 96  # H_net widths differ: no kernel
+    assert lib.phnn_weight_count(C.byref(d)) != blob.size
+
+
+def test_packer_errors():
+    with pytest.raises(ValueError):
+        weights.pack_state_dict({"foo": np.zeros(3)})
+    w = ol.load_weights("canonical_cartpole")
+    del w["M_net.b"]
+    with pytest.raises(ValueError):
+        weights.pack_state_dict(w)
+    wrapped = {"model_state_dict": ol.load_weights("phnn_pendulum")}
+    d, _ = weights.pack_state_dict(wrapped)
+    assert (d.kind, d.n, d.m, d.fixed_G) == (_capi.MODEL_PHNN, 2, 1, 0)
+
+
+def test_make_cost_rules():
+    c = _capi.make_cost(4, 1, [1, 2, 3, 4], 0.5, None, -1.0, None)  # one-sided bound: the reference does not clamp
+    assert c.has_u_bounds == 0 and c.Q[5] == 2.0 and c.R[0] == 0.5
+    with pytest.raises(ValueError):
+        _capi.make_cost(4, 1, np.eye(3), 0.1)
+
+
+# ----------------------------------------------------------------------------- model classes
+def test_model_state_dict_layout_matches_reference_checkpoints():
+    for cls, cfg, name in ((pHNN, CFG, "phnn_cartpole"), (pHNN_Canonical, CFG, "canonical_cartpole"),
+                           (pHNN, CFG_PEND, "phnn_pendulum")):
+        m = cls(cfg)
+        w = ol.load_weights(name)
+        assert set(m.state_dict().keys()) == set(w.keys())
+        m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})  # strict
+        d, blob = weights.pack_state_dict(m.state_dict())
+        d2, blob2 = weights.pack_state_dict(w)
+        assert np.array_equal(blob, blob2)
+    o = ODEFunc(2, 1)
+    w = ol.load_weights("odefunc_pendulum")
+    assert set(o.state_dict().keys()) == set(w.keys())
+    o.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+
+
+def test_seeded_construction_reproduces_reference_init():
+    """Same parameter-creation order and initialisers as the reference => same seed-0 weights (torch 2.10)."""
+    torch.manual_seed(0)
+    m = pHNN(CFG)
+    w = ol.load_weights("phnn_cartpole")
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.numpy(), w[k]), k
+
+
+def test_model_forward_through_engine_protocol():
+    w = ol.load_weights("phnn_cartpole")
+    g = ol.load_golden("phnn_cartpole")
+    m = pHNN(CFG)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    m.set_engine(OracleEngine(w))
+    x = torch.tensor(g["fwd_x"][:8], requires_grad=True)
+    u = torch.tensor(g["fwd_u"][:8], requires_grad=True)
+    dx, H = m(x, u)
+    assert np.allclose(dx.detach().numpy(), g["fwd_dx_f32"][:8], rtol=1e-5, atol=1e-6)
+    lam = torch.tensor(g["vjp_lam"][:8])
+    (dx * lam).sum().backward()
+    ref = ol.OracleModel(w, "f64").vjp(g["fwd_x"][:8], g["fwd_u"][:8], g["vjp_lam"][:8])
+    assert np.allclose(x.grad.numpy(), ref[0], rtol=1e-4, atol=1e-5)
+    assert np.allclose(u.grad.numpy(), ref[1], rtol=1e-4, atol=1e-5)
+    # 1-D input is promoted to a batch of one, as the reference does
+    dx1, H1 = m(torch.tensor(g["fwd_x"][0]), torch.tensor(g["fwd_u"][0]))
+    assert dx1.shape == (1, 4) and H1.shape == (1,)
+
+
+def test_unsupported_model_options_raise():
+    cfg = yaml.safe_load(open(CFG))
+    cfg["model"]["H_mlp"]["activation"] = "nn.ReLU"
+    p = os.path.join(ROOT, "gpurun_out", "_tmp_relu.yaml")
+    os.makedirs(os.path.dirname(p), exist_ok=True)
+    yaml.safe_dump(cfg, open(p, "w"))
+    m = pHNN(p)
+    with pytest.raises(NotImplementedError):
+        m.engine
+    with pytest.raises(ValueError):
+        ODEFunc(2, 1, activation="swish")
+    with pytest.raises(RuntimeError):
+        ODEFunc(2, 1)(0.0, torch.zeros(1, 2))
+
+
+# ----------------------------------------------------------------------------- controllers vs the reference
+def _phnn_with_oracle():
+    w = ol.load_weights("phnn_cartpole")
+    m = pHNN(CFG)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    return m.set_engine(OracleEngine(w))
+
+
+def _canon_with_oracle():
+    w = ol.load_weights("canonical_cartpole")
+    m = pHNN_Canonical(CFG)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    return m.set_engine(OracleEngine(w))
+
+
+def test_mpc_controller_matches_reference_g5(ctl):
+    cfg = yaml.safe_load(open(CFG))
+    c = create_mpc_from_config(_phnn_with_oracle(), cfg)
+    assert (c.horizon, c.lr, c.max_iterations) == (20, 0.015, 30)
+    u0 = c.compute_control(ctl["mpc_x0"].copy())
+    assert isinstance(u0, np.ndarray) and u0.shape == (1,)
+    assert abs(u0[0] - ctl["mpc_u0"][0]) < 2e-5, (u0, ctl["mpc_u0"])
+    out = c.solve_batch(ctl["mpc_x0"][None], record_costs=True)
+    assert np.allclose(out["costs"][:, 0].numpy(), ctl["mpc_costs"], rtol=2e-6)
+    # the controller's own B=1 rollout / cost methods
+    st = c.rollout_dynamics(torch.tensor(ctl["mpc_x0"]), torch.zeros(20, 1))
+    assert np.allclose(st.numpy(), ctl["mpc_zero_states"], atol=2e-6)
+    assert abs(float(c.compute_cost(st, torch.zeros(20, 1))) - float(ctl["mpc_zero_cost"])) < 1e-4
+
+
+def test_mpc_controller_other_schema_barrier_and_errors(ctl):
+    model = _phnn_with_oracle()
+    cfg = {"mpc": {"horizon": 20, "dt": 0.02, "Q": [10.0, 200.0, 1.0, 10.0], "R": 0.01, "u_min": -15.0, "u_max": 15.0,
+                   "x_min": list(ctl["bar_xmin"]), "x_max": list(ctl["bar_xmax"]), "lr": 0.015, "max_iterations": 5}}
+    c = create_mpc_from_config(model, cfg)
+    u0 = c.compute_control(ctl["mpc_x0"].copy())
+    assert abs(u0[0] - ctl["bar_u0_after5"][0]) < 2e-5
+    st = c.rollout_dynamics(torch.tensor(ctl["mpc_x0"]), torch.tensor(ctl["bar_u"]))
+    assert np.allclose(st.numpy(), ctl["bar_states"], atol=2e-6)
+    assert abs(float(c.compute_cost(st, torch.tensor(ctl["bar_u"]))) / float(ctl["bar_cost"]) - 1) < 1e-5
+    r = model.engine.rollout_cost_grad(torch.tensor(ctl["mpc_x0"][None]), torch.tensor(ctl["bar_u"][None]), c._cost(),
+                                       "euler", 0.02)
+    assert abs(float(r[0][0]) / float(ctl["bar_cost"]) - 1) < 1e-5
+    assert np.allclose(r[1][0].numpy(), ctl["bar_grad"], rtol=1e-4, atol=1e-4 * np.abs(ctl["bar_grad"]).max())
+    c.optimizer_type = "SGD"
+    with pytest.raises(ValueError):
+        c.compute_control(ctl["mpc_x0"].copy())
+
+
+def test_canonical_controller_matches_reference_g6(ctl):
+    cfg = yaml.safe_load(open(CFG))
+    c = create_mpc_controller(_canon_with_oracle(), cfg)
+    u_a, info_a = c.control(ctl["mpc_x0"].copy(), None)
+    assert u_a.shape == (1,) and info_a["u_sequence"].shape == (20, 1)
+    assert set(info_a) == {"u_sequence", "solve_time", "optimization"}
+    assert set(info_a["optimization"]) == {"costs", "final_cost", "num_steps"}
+    assert abs(u_a[0] - ctl["can_u_a"][0]) < 5e-5
+    assert np.allclose(info_a["optimization"]["costs"], ctl["can_costs_a"], rtol=5e-6)
+    assert abs(info_a["optimization"]["final_cost"] - float(ctl["can_final_a"])) < 1e-3
+    assert np.allclose(info_a["u_sequence"], ctl["can_useq_a"], atol=1e-4)
+    # warm start: shift by one, zero tail -- fed with the REFERENCE's previous sequence
+    u_b, info_b = c.control(ctl["can_x_b"].copy(), ctl["can_useq_a"])
+    assert abs(u_b[0] - ctl["can_u_b"][0]) < 1e-4
+    assert np.allclose(info_b["optimization"]["costs"], ctl["can_costs_b"], rtol=5e-6)
+    assert np.allclose(info_b["u_sequence"], ctl["can_useq_b"], atol=2e-4)
+
+
+def test_batched_solve_equals_per_sample_solves():
+    """B stacked problems behave exactly like B separate solves (Adam is element-wise, rollouts independent)."""
+    cfg = yaml.safe_load(open(CFG))
+    c = create_mpc_controller(_canon_with_oracle(), cfg)
+    c.optimizer_steps = 6
+    rng = np.random.default_rng(3)
+    X = (rng.uniform(-1, 1, size=(5, 4)) * [0.5, 0.2, 0.3, 0.3]).astype(np.float32)
+    ub, seq, best = c.control_batch(X)
+    for b in range(5):
+        u1, info = c.control(X[b])
+        assert np.array_equal(u1, ub[b]) and np.array_equal(info["u_sequence"], seq[b])

@@ -116,3 +116,13 @@ def test_dataset_windows_g8():
         assert ok.all()
         assert rel(r["cost"], win[f"{nm}_cost_f64"]) < 1e-10
         assert rel(r["grad_u"], win[f"{nm}_gu_f64"]) < 1e-8
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_rollout_vjp_with_trajectory_and_cost_cotangents_g10(bundle, integ):
+    """G10: loss = <W, traj> + <w, cost> differentiated by the reference's autograd (float64)."""
+    name, g, m64, _ = bundle
+    gu, gx = m64.rollout_vjp(g["tvjp_x0"], g["tvjp_U"], ol.cost_from_golden(g), integ, float(g["dt"]),
+                             traj_bar=g["tvjp_traj_bar"], cost_bar=g["tvjp_cost_bar"])
+    assert rel(gu, g[f"tvjp_{integ}_gu_f64"]) < 1e-9
+    assert rel(gx, g[f"tvjp_{integ}_gx0_f64"]) < 1e-9
