@@ -42,9 +42,14 @@ DEV f32x4 splat4(float s) { return f32x4{s, s, s, s}; }
 
 DEV float sel4(f32x4 v, int q) { return q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : v[3])); }
 
-// tanh in float32: odd minimax polynomial below 0.4 (rel. error 6e-8), 1 - 2/(1+e^{2|x|}) above
-// (abs. error ~1e-7), see DESIGN.md "numerics".
+// tanh in float32.  f32 MFMA and VALU share the SIMD's vector ALUs on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0
+// for this kernel), so every VALU cycle spent here is a cycle the MFMAs do not get: tanh is 384 evaluations
+// per rollout-step and was 80 % of the non-MFMA vector time with the two-branch form.
+//   default  : 1 - 2/(1 + 2^(2x*log2 e)), 5 instructions, abs. error <= 2.5e-7 everywhere (relative error
+//              grows towards x = 0 but the absolute error is what propagates through the sums)
+//   -DPHNN_TANH_ACCURATE : odd minimax polynomial below 0.4 (rel. 6e-8) + the same formula above (abs. 1e-7)
 DEV float tanh_dev(float x) {
+#ifdef PHNN_TANH_ACCURATE
   float ax = __builtin_fabsf(x);
   float s = x * x;
   float p = -0.007265716325491667f;
@@ -57,6 +62,10 @@ DEV float tanh_dev(float x) {
   float big = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
   float r = ax < 0.4f ? small : big;
   return __builtin_copysignf(r, x);
+#else
+  float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+#endif
 }
 
 // sin and cos in float32: 3-term Cody-Waite reduction by pi/2 (exact first step through the fma) and
@@ -122,39 +131,68 @@ DEV void in_layer(Act<T>& o, const float* Wf, Lane ln, float xk) {
 }
 
 // o += W * in : W is a padded row-major image [16*TO][LD], LD = 16*TI + 4.
+// Software-pipelined: the A fragments (weights) of group g+1 are requested from LDS before the MFMAs of group
+// g are issued, and sched_group_barrier pins that order, so the LDS latency sits under 16 MFMAs (512 matrix-
+// pipe cycles) instead of in front of them.
 template <int TO, int TI>
 DEV void sq_fwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
   constexpr int LD = 16 * TI + 4;
   keep_lds_reads_local();
   const float* base = W + ln.i * LD + 4 * ln.q;
-  constexpr int G = TO < 4 ? TO : 4;  // output tiles in flight: 4 independent accumulation chains
+  constexpr int G = TO < 4 ? TO : 4;  // output tiles in flight: G independent accumulation chains
+  constexpr int NG = (TO / G) * TI;   // groups of 4*G MFMAs
+  f32x4 a[G], an[G];
 #pragma unroll
-  for (int t = 0; t < TI; ++t) {
+  for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4*>(base + g * 16 * LD);
 #pragma unroll
-    for (int n0 = 0; n0 < TO; n0 += G) {
-      f32x4 a[G];
+  for (int grp = 0; grp < NG; ++grp) {
+    const int t = grp / (TO / G), n0 = (grp % (TO / G)) * G;
+    if (grp + 1 < NG) {
+      const int t1 = (grp + 1) / (TO / G), m0 = ((grp + 1) % (TO / G)) * G;
 #pragma unroll
-      for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4*>(base + (n0 + g) * 16 * LD + 16 * t);
+      for (int g = 0; g < G; ++g) an[g] = *reinterpret_cast<const f32x4*>(base + (m0 + g) * 16 * LD + 16 * t1);
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int g = 0; g < G; ++g) o.v[n0 + g] = mfma(a[g][r], in.v[t][r], o.v[n0 + g]);
+      for (int g = 0; g < G; ++g) o.v[n0 + g] = mfma(a[g][r], in.v[t][r], o.v[n0 + g]);
+    if (grp + 1 < NG) {
+      __builtin_amdgcn_sched_group_barrier(0x100, G, 0);      // G DS reads (next group)
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * G, 0);  // 4G MFMAs (this group)
+#pragma unroll
+      for (int g = 0; g < G; ++g) a[g] = an[g];
     }
   }
 }
 
-// o += W^T * in : same image [16*TI][LD], LD = 16*TO + 4 (TO = tiles of the columns of W).
+// o += W^T * in : same image [16*TI][LD], LD = 16*TO + 4 (TO = tiles of the columns of W).  Columns on
+// lanes: one ds_read_b32 per MFMA, pipelined one group (TO MFMAs) ahead like sq_fwd.
 template <int TO, int TI>
 DEV void sq_bwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
   constexpr int LD = 16 * TO + 4;
   keep_lds_reads_local();
   const float* base = W + 4 * ln.q * LD + ln.i;
+  constexpr int NG = 4 * TI;
+  float a[TO], an[TO];
 #pragma unroll
-  for (int t = 0; t < TI; ++t)
+  for (int nt = 0; nt < TO; ++nt) a[nt] = base[16 * nt];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+  for (int grp = 0; grp < NG; ++grp) {
+    const int t = grp / 4, r = grp % 4;
+    if (grp + 1 < NG) {
+      const int row = 16 * ((grp + 1) / 4) + (grp + 1) % 4;
 #pragma unroll
-      for (int nt = 0; nt < TO; ++nt) o.v[nt] = mfma(base[(16 * t + r) * LD + 16 * nt], in.v[t][r], o.v[nt]);
+      for (int nt = 0; nt < TO; ++nt) an[nt] = base[row * LD + 16 * nt];
+    }
+#pragma unroll
+    for (int nt = 0; nt < TO; ++nt) o.v[nt] = mfma(a[nt], in.v[t][r], o.v[nt]);
+    if (grp + 1 < NG) {
+      __builtin_amdgcn_sched_group_barrier(0x100, TO, 0);  // DS reads of the next group (pairs may fuse to read2)
+      __builtin_amdgcn_sched_group_barrier(0x008, TO, 0);  // MFMAs of this group
+#pragma unroll
+      for (int nt = 0; nt < TO; ++nt) a[nt] = an[nt];
+    }
+  }
 }
 
 // 16*TI units -> 4 outputs, every lane receives all 4 (row 4q+r of the MFMA tile carries output r).
@@ -669,6 +707,7 @@ struct RollParams {
   float* grad_x0;      // (B,N) or null
   long long B;
   int H;
+  int stagger;  // waves of the second half of a workgroup start this many s_sleep(127) late (see stagger_waves)
   float dt, half_dt, sixth_dt;
   phnn_cost c;
 };
@@ -689,6 +728,15 @@ DEV void stage_image(float* lds, const float* img) {
   f32x4* dst = reinterpret_cast<f32x4*>(lds);
   for (int k = threadIdx.x; k < IMG / 4; k += blockDim.x) dst[k] = src[k];
   __syncthreads();
+}
+
+// The two waves that share a SIMD (w and w + nwaves/2) run the same program; started together they stay in
+// phase -- both in their MFMA blocks (halving each other's rate), then both in their tanh/VALU blocks (matrix
+// pipe idle).  Starting the second half late by a fraction of a step lets one wave's VALU phases fall under
+// the other's MFMA phases (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+DEV void stagger_waves(int wave, int nwaves, int sleeps) {
+  if (nwaves >= 2 && wave >= (nwaves + 1) / 2)
+    for (int k = 0; k < sleeps; ++k) __builtin_amdgcn_s_sleep(127);
 }
 
 template <int N>
@@ -729,6 +777,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   const bool valid = b < p.B;
   if (!valid) b = p.B - 1;
   const float* L = lds;
+  stagger_waves(wave, nwaves, p.stagger);
   f32x4 x = load_state<N>(p.x0 + b * N);
   const bool writer = valid && ln.q == 0;
   if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1)) * N, x);
@@ -771,6 +820,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   const bool valid = b < p.B;
   if (!valid) b = p.B - 1;
   const float* L = lds;
+  stagger_waves(wave, nwaves, p.stagger);
   const bool writer = valid && ln.q == 0;
   const float* tr = p.traj_in + (b * (p.H + 1)) * N;
   const float* up = p.u + b * p.H;

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 namespace {
 
 thread_local std::string g_create_error;
+constexpr int kDefaultStagger = 0;
 
 enum Variant {
   V_NONE = 0,
@@ -309,6 +311,7 @@ struct phnn_handle {
   KernelSet ks;
   float* d_img;
   int n_cu;
+  int stagger;  // s_sleep(127) count for the late half of each workgroup (tuning knob, env PHNN_STAGGER)
   std::string err;
 };
 
@@ -328,6 +331,10 @@ int hip_fail(phnn_handle* h, hipError_t e, const char* what) {
 // workgroup; fewer waves per workgroup for small batches so the tiles spread over the CUs.
 int pick_waves(long long tiles, int n_cu) {
   int w = kMaxWaves;
+  if (const char* e = getenv("PHNN_MAX_WAVES")) {  // tuning knob
+    int v = atoi(e);
+    if (v >= 1 && v <= kMaxWaves) w = v;
+  }
   while (w > 1 && (tiles + w - 1) / w < n_cu) w >>= 1;
   return w;
 }
@@ -400,6 +407,8 @@ int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_float
   h->device = device;
   h->variant = v;
   kernel_set(v, &h->ks);
+  h->stagger = kDefaultStagger;
+  if (const char* e = getenv("PHNN_STAGGER")) h->stagger = atoi(e);
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device);
   h->n_cu = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -466,6 +475,7 @@ static int fill_roll(phnn_handle* h, RollParams* p, const float* x0, const float
   p->half_dt = (float)(dtd / 2);
   p->sixth_dt = (float)(dtd / 6.0);
   p->c = *cost;
+  p->stagger = h->stagger;
   return PHNN_OK;
 }
 
