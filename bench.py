@@ -48,6 +48,7 @@ def parse():
                     choices=["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum"])
     ap.add_argument("--integrator", default="euler", choices=["euler", "rk4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stash", action="store_true", help="K2 recomputes the forward tape instead of reading K1's")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="rollouts timed on the host for cpu_baseline")
     return ap.parse_args()
 
@@ -98,11 +99,13 @@ def main():
     def step(ev=None):
         if ev is not None:
             ev[0].record()
-        c = eng.rollout_cost(x0, U, cost, args.integrator, dt, traj_out=ws_traj)[0]
+        eng.lib.phnn_rollout_fwd(eng.h, eng._p(x0), eng._p(U), B, H, cost_ref, integ, float(dt), eng._p(ws_cost),
+                                 eng._p(ws_traj), eng._p(ws_stash), eng._stream())
+        c = ws_cost
         if ev is not None:
             ev[1].record()
         eng.lib.phnn_rollout_grad(eng.h, eng._p(x0), eng._p(U), B, H, cost_ref, integ, float(dt), eng._p(ws_traj),
-                                  eng._p(ws_gu), None, eng._stream())
+                                  eng._p(ws_stash), eng._p(ws_gu), None, eng._stream())
         if ev is not None:
             ev[2].record()
         if world > 1:
@@ -114,6 +117,9 @@ def main():
     integ = _capi.INTEGRATORS[args.integrator]
     ws_traj = torch.empty(B, H + 1, n, dtype=torch.float32, device=dev)
     ws_gu = torch.empty(B, H, 1, dtype=torch.float32, device=dev)
+    ws_cost = torch.empty(B, dtype=torch.float32, device=dev)
+    nstash = eng.workspace_bytes(B, H, integ) if (eng.use_stash and not args.no_stash) else 0
+    ws_stash = torch.empty(nstash, dtype=torch.uint8, device=dev) if nstash > 0 else None
 
     for _ in range(args.warmup):
         step()
@@ -165,7 +171,7 @@ def main():
             "config": {"workload": f"{args.model} (seed-0 fixture weights) {args.integrator} H={H} "
                                    f"B={B}/GPU: rollout + stage cost (K1) + control gradient (K2)"
                                    + (" + RCCL all-gather of costs" if world > 1 else ""),
-                       "horizon": H, "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"shard{world}"},
+                       "k2_mode": "stash" if ws_stash is not None else "recompute", "horizon": H, "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"shard{world}"},
             "roofline": roof,
         }
         if cpu is not None:

@@ -121,7 +121,15 @@ int phnn_model_vjp(phnn_handle* h, const float* x_dev, const float* u_dev, const
  *   trajectory nor a later phnn_rollout_grad is wanted). */
 int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
                      const phnn_cost* cost, int32_t integrator, float dt, float* cost_dev, float* traj_dev,
-                     void* stream);
+                     void* workspace_dev, void* stream);
+
+/* Optional K1 -> K2 workspace.  With workspace_dev != NULL (at least phnn_workspace_bytes() bytes, Euler
+ * only) K1 also streams the H_net / network activations of every step to it and K2, given the same pointer,
+ * reads them back instead of re-evaluating the forward pass: about half of K2's matrix work for
+ * 1.5 KB per rollout-step of extra HBM traffic each way (cart-pole).  Returns 0 when the integrator has no
+ * stash variant (RK4), in which case NULL must be passed.  The workspace passed to phnn_rollout_grad /
+ * phnn_rollout_vjp must have been filled by phnn_rollout_fwd with the same (x0, u, B, H, cost, dt). */
+size_t phnn_workspace_bytes(const phnn_handle* h, int64_t B, int32_t H, int32_t integrator);
 
 /* K2 -- adjoint march: replaces cost.backward() (src/mpc_controller.py:192,
  * src/mpc_controller_canonical.py:205).  Reads the states K1 wrote to traj_dev, re-evaluates the
@@ -129,7 +137,7 @@ int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, in
  * H_net).  -> grad_u_dev (B,H,m) = d cost_b / d u_b (unclamped), grad_x0_dev (B,n) or NULL. */
 int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
                       const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
-                      float* grad_u_dev, float* grad_x0_dev, void* stream);
+                      const void* workspace_dev, float* grad_u_dev, float* grad_x0_dev, void* stream);
 
 /* General reverse pass of the rollout, what autograd does when a loss is built on BOTH outputs of
  * rollout_trajectory_differentiable + compute_cost (src/integrators.py:192-258): given cotangents
@@ -138,8 +146,8 @@ int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, i
  * traj_bar = 0, cost_bar = 1. */
 int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
                      const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
-                     const float* traj_bar_dev, const float* cost_bar_dev, float* grad_u_dev, float* grad_x0_dev,
-                     void* stream);
+                     const void* workspace_dev, const float* traj_bar_dev, const float* cost_bar_dev,
+                     float* grad_u_dev, float* grad_x0_dev, void* stream);
 
 /* K3 -- Adam step on the controls, arithmetic order of torch.optim.Adam (single-tensor, defaults:
  * no weight decay / amsgrad) as used by src/mpc_controller.py:168,200 and

@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libphnn_mpc.so")
 # every symbol include/phnn_mpc.h declares
 EXPORTED = [
     "phnn_create", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
-    "phnn_model_vjp", "phnn_rollout_fwd", "phnn_rollout_grad", "phnn_rollout_vjp", "phnn_adam_step", "phnn_kernel_info",
+    "phnn_model_vjp", "phnn_rollout_fwd", "phnn_workspace_bytes", "phnn_rollout_grad", "phnn_rollout_vjp",
+    "phnn_adam_step", "phnn_kernel_info",
     "phnn_version",
 ]
 
@@ -123,12 +124,15 @@ def load_library():
     lib.phnn_model_forward.restype = C.c_int
     lib.phnn_model_vjp.argtypes = [vp, f32p, f32p, f32p, i64, f32p, f32p, vp]
     lib.phnn_model_vjp.restype = C.c_int
-    lib.phnn_rollout_fwd.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, vp]
+    lib.phnn_rollout_fwd.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, vp, vp]
     lib.phnn_rollout_fwd.restype = C.c_int
-    lib.phnn_rollout_grad.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, f32p, vp]
+    lib.phnn_workspace_bytes.argtypes = [vp, i64, i32, i32]
+    lib.phnn_workspace_bytes.restype = C.c_size_t
+    lib.phnn_rollout_grad.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, vp, f32p, f32p,
+                                      vp]
     lib.phnn_rollout_grad.restype = C.c_int
-    lib.phnn_rollout_vjp.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, f32p, f32p, f32p,
-                                     f32p, vp]
+    lib.phnn_rollout_vjp.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, vp, f32p, f32p,
+                                     f32p, f32p, vp]
     lib.phnn_rollout_vjp.restype = C.c_int
     lib.phnn_adam_step.argtypes = [vp, f32p, f32p, f32p, f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32,
                                    f32p, f32p, f32p, i64, C.c_float, C.c_float, i32, vp]

@@ -130,69 +130,44 @@ DEV void in_layer(Act<T>& o, const float* Wf, Lane ln, float xk) {
   for (int nt = 0; nt < T; ++nt) o.v[nt] = mfma(Wf[nt * 64 + ln.lane], xk, o.v[nt]);
 }
 
-// o += W * in : W is a padded row-major image [16*TO][LD], LD = 16*TI + 4.
-// Software-pipelined: the A fragments (weights) of group g+1 are requested from LDS before the MFMAs of group
-// g are issued, and sched_group_barrier pins that order, so the LDS latency sits under 16 MFMAs (512 matrix-
-// pipe cycles) instead of in front of them.
+// o += W * in : W is a padded row-major image [16*TO][LD], LD = 16*TI + 4.  Rows on lanes: one ds_read_b128
+// feeds 4 k-steps; G output tiles (independent accumulation chains) are in flight per group.
+// (A hand-pipelined variant with sched_group_barrier, prefetching the next group's fragments, was measured:
+// K1 -2.5 %, K2 +3.7 % (more spills), and the IGroupLP solver multiplied compile time by ~15: not kept.)
 template <int TO, int TI>
 DEV void sq_fwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
   constexpr int LD = 16 * TI + 4;
   keep_lds_reads_local();
   const float* base = W + ln.i * LD + 4 * ln.q;
-  constexpr int G = TO < 4 ? TO : 4;  // output tiles in flight: G independent accumulation chains
-  constexpr int NG = (TO / G) * TI;   // groups of 4*G MFMAs
-  f32x4 a[G], an[G];
+  constexpr int G = TO < 4 ? TO : 4;
 #pragma unroll
-  for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4*>(base + g * 16 * LD);
+  for (int t = 0; t < TI; ++t) {
 #pragma unroll
-  for (int grp = 0; grp < NG; ++grp) {
-    const int t = grp / (TO / G), n0 = (grp % (TO / G)) * G;
-    if (grp + 1 < NG) {
-      const int t1 = (grp + 1) / (TO / G), m0 = ((grp + 1) % (TO / G)) * G;
+    for (int n0 = 0; n0 < TO; n0 += G) {
+      f32x4 a[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) an[g] = *reinterpret_cast<const f32x4*>(base + (m0 + g) * 16 * LD + 16 * t1);
-    }
+      for (int g = 0; g < G; ++g) a[g] = *reinterpret_cast<const f32x4*>(base + (n0 + g) * 16 * LD + 16 * t);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int g = 0; g < G; ++g) o.v[n0 + g] = mfma(a[g][r], in.v[t][r], o.v[n0 + g]);
-    if (grp + 1 < NG) {
-      __builtin_amdgcn_sched_group_barrier(0x100, G, 0);      // G DS reads (next group)
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * G, 0);  // 4G MFMAs (this group)
-#pragma unroll
-      for (int g = 0; g < G; ++g) a[g] = an[g];
+        for (int g = 0; g < G; ++g) o.v[n0 + g] = mfma(a[g][r], in.v[t][r], o.v[n0 + g]);
     }
   }
 }
 
 // o += W^T * in : same image [16*TI][LD], LD = 16*TO + 4 (TO = tiles of the columns of W).  Columns on
-// lanes: one ds_read_b32 per MFMA, pipelined one group (TO MFMAs) ahead like sq_fwd.
+// lanes: one ds_read_b32 per MFMA (pairs fuse to ds_read2_b32), bank-conflict-free.
 template <int TO, int TI>
 DEV void sq_bwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
   constexpr int LD = 16 * TO + 4;
   keep_lds_reads_local();
   const float* base = W + 4 * ln.q * LD + ln.i;
-  constexpr int NG = 4 * TI;
-  float a[TO], an[TO];
 #pragma unroll
-  for (int nt = 0; nt < TO; ++nt) a[nt] = base[16 * nt];
+  for (int t = 0; t < TI; ++t)
 #pragma unroll
-  for (int grp = 0; grp < NG; ++grp) {
-    const int t = grp / 4, r = grp % 4;
-    if (grp + 1 < NG) {
-      const int row = 16 * ((grp + 1) / 4) + (grp + 1) % 4;
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int nt = 0; nt < TO; ++nt) an[nt] = base[row * LD + 16 * nt];
-    }
-#pragma unroll
-    for (int nt = 0; nt < TO; ++nt) o.v[nt] = mfma(a[nt], in.v[t][r], o.v[nt]);
-    if (grp + 1 < NG) {
-      __builtin_amdgcn_sched_group_barrier(0x100, TO, 0);  // DS reads of the next group (pairs may fuse to read2)
-      __builtin_amdgcn_sched_group_barrier(0x008, TO, 0);  // MFMAs of this group
-#pragma unroll
-      for (int nt = 0; nt < TO; ++nt) a[nt] = an[nt];
-    }
-  }
+      for (int nt = 0; nt < TO; ++nt) o.v[nt] = mfma(base[(16 * t + r) * LD + 16 * nt], in.v[t][r], o.v[nt]);
 }
 
 // 16*TI units -> 4 outputs, every lane receives all 4 (row 4q+r of the MFMA tile carries output r).
@@ -213,6 +188,19 @@ DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
     }
   }
   return o0 + o1;
+}
+
+// Per-wave stash in HBM (K1 -> K2): one activation vector = T x 64 lanes x float4, i.e. one fully coalesced
+// 1 KB store/load per tile.  Streamed once each way, so non-temporal.
+template <int T>
+DEV void store_act(float* dst, Lane ln, const Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) __builtin_nontemporal_store(a.v[t], reinterpret_cast<f32x4*>(dst) + t * 64 + ln.lane);
+}
+template <int T>
+DEV void load_act(const float* src, Lane ln, Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) a.v[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + t * 64 + ln.lane);
 }
 
 // 16 per-rollout values spread over the 4 lanes of a rollout (lane (i,q) holds values 4q..4q+3) ->
@@ -383,12 +371,21 @@ struct PhnnModel {
   static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
   static constexpr int IMG = oG + 4;
 
-  // dx = (Jeff - S S^T) dH + G u, with S = sym(R_raw)
-  template <bool WANT_H>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval) {
+  // floats one wave stashes per step for the adjoint: a1, a2, q1 (T x 256 each) + dH (16 x 4)
+  static constexpr int STASH = 3 * T * 256 + 64;
+
+  // dx = (Jeff - S S^T) dH + G u, with S = sym(R_raw).  stash != null: keep the H_net tape for K2.
+  template <bool WANT_H, bool ST = false>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     HTape<HID> tp;
     f32x4 dH = hnet_grad<HID, WANT_H>(L + oH, ln, x, tp, Hval);
+    if (ST) {
+      store_act<T>(stash, ln, tp.a1);
+      store_act<T>(stash + T * 256, ln, tp.a2);
+      store_act<T>(stash + 2 * T * 256, ln, tp.q1);
+      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 3 * T * 256) + ln.i);
+    }
     Act<T> hR;
     float rf[16];
     h1_fwd<HID>(L + oR, scr, ln, x, hR, rf);
@@ -433,11 +430,21 @@ struct PhnnModel {
   }
 
   // xbar = (df/dx)^T lam, ubar = (df/du)^T lam at (x,u); recomputes the forward tape it needs.
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar) {
+  template <bool ST = false>
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar,
+                      const float* stash = nullptr) {
     keep_lds_reads_local();
     HTape<HID> tp;
     float Hdummy;
-    f32x4 dH = hnet_grad<HID, false>(L + oH, ln, x, tp, Hdummy);
+    f32x4 dH;
+    if (ST) {  // tape written by K1: the loads fly while the R_net part below runs
+      load_act<T>(stash, ln, tp.a1);
+      load_act<T>(stash + T * 256, ln, tp.a2);
+      load_act<T>(stash + 2 * T * 256, ln, tp.q1);
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
+    } else {
+      dH = hnet_grad<HID, false>(L + oH, ln, x, tp, Hdummy);
+    }
     f32x4 xb = splat4(0.f);
     float S[N][N], Stl[N], StdH[N];
     {
@@ -516,8 +523,10 @@ struct CanonModel {
   static constexpr int oC = oH + LayH2<HID>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
   static constexpr int IMG = oC + 12;
 
-  template <bool WANT_H>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, float u, float& Hval) {
+  static constexpr int STASH = 3 * T * 256 + 64;
+
+  template <bool WANT_H, bool ST = false>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, float u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
     float sn, cs;
@@ -526,6 +535,12 @@ struct CanonModel {
     f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
     HTape<HID> tp;
     f32x4 dH = hnet_grad<HID, WANT_H>(L + oH, ln, z, tp, Hval);
+    if (ST) {
+      store_act<T>(stash, ln, tp.a1);
+      store_act<T>(stash + T * 256, ln, tp.a2);
+      store_act<T>(stash + 2 * T * 256, ln, tp.q1);
+      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 3 * T * 256) + ln.i);
+    }
     float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + L[oC + 10] * u;
     float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + L[oC + 11] * u;
     float det = (a * c - bc * bc) + 1e-6f;
@@ -534,7 +549,9 @@ struct CanonModel {
                  mi01 * dp0 + mi11 * dp1};
   }
 
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, float u, f32x4 lam, f32x4& ybar, float& ubar) {
+  template <bool ST = false>
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, float u, f32x4 lam, f32x4& ybar, float& ubar,
+                      const float* stash = nullptr) {
     keep_lds_reads_local();
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
     float sn, cs;
@@ -543,7 +560,15 @@ struct CanonModel {
     f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
     HTape<HID> tp;
     float Hdummy;
-    f32x4 dH = hnet_grad<HID, false>(L + oH, ln, z, tp, Hdummy);
+    f32x4 dH;
+    if (ST) {
+      load_act<T>(stash, ln, tp.a1);
+      load_act<T>(stash + T * 256, ln, tp.a2);
+      load_act<T>(stash + 2 * T * 256, ln, tp.q1);
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
+    } else {
+      dH = hnet_grad<HID, false>(L + oH, ln, z, tp, Hdummy);
+    }
     float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
     float dp0 = (-dH[0] - Rd2 * dH[2]) + L[oC + 10] * u;
     float dp1 = (-dH[1] - Rd3 * dH[3]) + L[oC + 11] * u;
@@ -607,16 +632,32 @@ struct OdeModel {
     return to4_rep<T>(L + oW4r, ln, tp.a3) + b4;
   }
 
-  template <bool WANT_H>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval) {
+  static constexpr int STASH = 3 * T * 256;
+
+  template <bool WANT_H, bool ST = false>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
     Tape tp;
     if (WANT_H) Hval = 0.f;
-    return fwd(L, ln, x, u, tp);
+    f32x4 dx = fwd(L, ln, x, u, tp);
+    if (ST) {
+      store_act<T>(stash, ln, tp.a1);
+      store_act<T>(stash + T * 256, ln, tp.a2);
+      store_act<T>(stash + 2 * T * 256, ln, tp.a3);
+    }
+    return dx;
   }
 
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar) {
+  template <bool ST = false>
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar,
+                      const float* stash = nullptr) {
     Tape tp;
-    (void)fwd(L, ln, x, u, tp);
+    if (ST) {
+      load_act<T>(stash, ln, tp.a1);
+      load_act<T>(stash + T * 256, ln, tp.a2);
+      load_act<T>(stash + 2 * T * 256, ln, tp.a3);
+    } else {
+      (void)fwd(L, ln, x, u, tp);
+    }
     Act<T> d, e;
     zero_act<T>(d);
     in_layer<T>(d, L + oW4f, ln, sel4(lam, ln.q));
@@ -705,6 +746,7 @@ struct RollParams {
   float* traj;         // (B,H+1,N) or null
   float* grad_u;       // (B,H)
   float* grad_x0;      // (B,N) or null
+  float* stash;        // K1 -> K2 tape workspace (Euler only) or null: [tile][t][M::STASH] floats
   long long B;
   int H;
   int stagger;  // waves of the second half of a workgroup start this many s_sleep(127) late (see stagger_waves)
@@ -760,7 +802,7 @@ DEV void store_state(float* p, f32x4 x) {
 DEV float clamp_u(const phnn_cost& c, float u) { return c.has_u_bounds ? fminf(fmaxf(u, c.u_min), c.u_max) : u; }
 
 // K1: forward march.  One wave = 16 rollouts; grid x = ceil(B/16/waves).
-template <class M, int INTEG>
+template <class M, int INTEG, bool STASH>
 __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int N = M::N;
@@ -787,7 +829,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   for (int t = 0; t < p.H; ++t) {
     float u = clamp_u(p.c, up[t]);
     cost = __builtin_fmaf(u * p.c.R[0], u, cost);
-    f32x4 k1 = M::template f<false>(L, scr, ln, x, u, Hd);
+    f32x4 k1 = M::template f<false, STASH>(L, scr, ln, x, u, Hd,
+                                           STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr);
     if (INTEG == PHNN_INTEG_EULER) {
       x = x + p.dt * k1;
     } else {
@@ -803,7 +846,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
 }
 
 // K2: adjoint march over the states K1 stored.
-template <class M, int INTEG>
+template <class M, int INTEG, bool STASH>
 __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int N = M::N;
@@ -836,7 +879,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
     f32x4 xb;
     float ub, utot;
     if (INTEG == PHNN_INTEG_EULER) {
-      M::vjp(L, scr, ln, x, u, p.dt * lam, xb, ub);
+      M::template vjp<STASH>(L, scr, ln, x, u, p.dt * lam, xb, ub,
+                             STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr);
       lam = lam + xb;
       utot = ub;
     } else {

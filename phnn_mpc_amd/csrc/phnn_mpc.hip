@@ -43,6 +43,9 @@ using M_ODE_3_128 = OdeModel<3, 128>;
 struct KernelSet {
   void (*fwd[2])(RollParams);
   void (*grad[2])(RollParams);
+  void (*fwd_stash)(RollParams);   // Euler, K1 keeps the tape for K2
+  void (*grad_stash)(RollParams);  // Euler, K2 reads the tape instead of recomputing it
+  int stash_floats;                // per wave (16 rollouts) per step
   void (*mfwd)(PointParams);
   void (*mvjp)(PointParams);
   int img_floats;
@@ -52,10 +55,13 @@ struct KernelSet {
 template <class M>
 KernelSet make_set(const char* name) {
   KernelSet k;
-  k.fwd[0] = k_rollout_fwd<M, PHNN_INTEG_EULER>;
-  k.fwd[1] = k_rollout_fwd<M, PHNN_INTEG_RK4>;
-  k.grad[0] = k_rollout_grad<M, PHNN_INTEG_EULER>;
-  k.grad[1] = k_rollout_grad<M, PHNN_INTEG_RK4>;
+  k.fwd[0] = k_rollout_fwd<M, PHNN_INTEG_EULER, false>;
+  k.fwd[1] = k_rollout_fwd<M, PHNN_INTEG_RK4, false>;
+  k.grad[0] = k_rollout_grad<M, PHNN_INTEG_EULER, false>;
+  k.grad[1] = k_rollout_grad<M, PHNN_INTEG_RK4, false>;
+  k.fwd_stash = k_rollout_fwd<M, PHNN_INTEG_EULER, true>;
+  k.grad_stash = k_rollout_grad<M, PHNN_INTEG_EULER, true>;
+  k.stash_floats = M::STASH;
   k.mfwd = k_model_forward<M>;
   k.mvjp = k_model_vjp<M>;
   k.img_floats = M::IMG;
@@ -479,9 +485,15 @@ static int fill_roll(phnn_handle* h, RollParams* p, const float* x0, const float
   return PHNN_OK;
 }
 
+size_t phnn_workspace_bytes(const phnn_handle* h, int64_t B, int32_t H, int32_t integrator) {
+  if (!h || B <= 0 || H < 1 || integrator != PHNN_INTEG_EULER) return 0;
+  size_t tiles = (size_t)((B + kTileB - 1) / kTileB);
+  return tiles * (size_t)H * (size_t)h->ks.stash_floats * sizeof(float);
+}
+
 int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
                      const phnn_cost* cost, int32_t integrator, float dt, float* cost_dev, float* traj_dev,
-                     void* stream) {
+                     void* workspace_dev, void* stream) {
   if (!h) return PHNN_ERR_INVALID_ARG;
   RollParams p;
   if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
@@ -490,28 +502,23 @@ int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   if (int rc = check_device(h)) return rc;
   p.cost = cost_dev;
   p.traj = traj_dev;
-  return launch(h, h->ks.fwd[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+  const bool stash = workspace_dev && integrator == PHNN_INTEG_EULER;
+  p.stash = stash ? (float*)workspace_dev : nullptr;
+  return launch(h, stash ? h->ks.fwd_stash : h->ks.fwd[integrator], p, (B + kTileB - 1) / kTileB, false,
+                (hipStream_t)stream);
 }
 
 int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
-                      const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev, float* grad_u_dev,
-                      float* grad_x0_dev, void* stream) {
-  if (!h) return PHNN_ERR_INVALID_ARG;
-  RollParams p;
-  if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
-  if (!traj_dev || !grad_u_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev / grad_u_dev is NULL");
-  if (B == 0) return PHNN_OK;
-  if (int rc = check_device(h)) return rc;
-  p.traj_in = traj_dev;
-  p.grad_u = grad_u_dev;
-  p.grad_x0 = grad_x0_dev;
-  return launch(h, h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+                      const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
+                      const void* workspace_dev, float* grad_u_dev, float* grad_x0_dev, void* stream) {
+  return phnn_rollout_vjp(h, x0_dev, u_dev, B, H, cost, integrator, dt, traj_dev, workspace_dev, nullptr, nullptr,
+                          grad_u_dev, grad_x0_dev, stream);
 }
 
 int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
                      const phnn_cost* cost, int32_t integrator, float dt, const float* traj_dev,
-                     const float* traj_bar_dev, const float* cost_bar_dev, float* grad_u_dev, float* grad_x0_dev,
-                     void* stream) {
+                     const void* workspace_dev, const float* traj_bar_dev, const float* cost_bar_dev,
+                     float* grad_u_dev, float* grad_x0_dev, void* stream) {
   if (!h) return PHNN_ERR_INVALID_ARG;
   RollParams p;
   if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
@@ -523,7 +530,10 @@ int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   p.cost_bar = cost_bar_dev;
   p.grad_u = grad_u_dev;
   p.grad_x0 = grad_x0_dev;
-  return launch(h, h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+  const bool stash = workspace_dev && integrator == PHNN_INTEG_EULER;
+  p.stash = stash ? (float*)workspace_dev : nullptr;
+  return launch(h, stash ? h->ks.grad_stash : h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false,
+                (hipStream_t)stream);
 }
 
 int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,

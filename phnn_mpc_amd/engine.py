@@ -4,6 +4,7 @@ torch is plumbing here (device memory, streams); all arithmetic happens in the g
 csrc/libphnn_mpc.so.  There is no fallback: without the library or without a GPU, construction raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,10 @@ class RolloutEngine:
             raise PhnnError("no GPU visible to torch; the rollout engine has no CPU fallback")
         self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind)
         self.n, self.m, self.kind = self.desc.n, self.desc.m, self.desc.kind
+        # K1 -> K2 activation stash (Euler): on unless PHNN_NO_STASH=1; capped so a huge batch falls back to
+        # the recompute kernels instead of allocating more than max_stash_bytes of HBM
+        self.use_stash = os.environ.get("PHNN_NO_STASH", "0") != "1"
+        self.max_stash_bytes = int(float(os.environ.get("PHNN_MAX_STASH_GB", "96")) * (1 << 30))
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
         h = C.c_void_p()
@@ -113,9 +118,12 @@ class RolloutEngine:
         if traj is None and want_traj:
             traj = torch.empty(B, H + 1, self.n, dtype=torch.float32, device=self.device)
         rc = self.lib.phnn_rollout_fwd(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), self._integ(integrator),
-                                       float(dt), self._p(c), self._p(traj), self._stream())
+                                       float(dt), self._p(c), self._p(traj), None, self._stream())
         _check(self.lib, self.h, rc)
         return (c, traj) if (want_traj or traj_out is not None) else c
+
+    def workspace_bytes(self, B, H, integrator="euler"):
+        return int(self.lib.phnn_workspace_bytes(self.h, int(B), int(H), self._integ(integrator)))
 
     def rollout_cost_grad(self, x0, u, cost, integrator="euler", dt=0.02, want_grad_x0=False, workspace=None):
         """K1 + K2.  -> (cost (B), grad_u (B,H,m)[, grad_x0 (B,n)]).  `workspace`: optional dict reused across
@@ -125,20 +133,24 @@ class RolloutEngine:
         u = self._t(u).reshape(B, -1, self.m)
         H = u.shape[1]
         ws = workspace if workspace is not None else {}
-        key = (B, H)
+        integ = self._integ(integrator)
+        key = (B, H, integ)
         if ws.get("key") != key:
             ws["key"] = key
+            nbytes = self.workspace_bytes(B, H, integ) if self.use_stash else 0
+            ws["stash"] = (torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                           if 0 < nbytes <= self.max_stash_bytes else None)
             ws["traj"] = torch.empty(B, H + 1, self.n, dtype=torch.float32, device=self.device)
             ws["cost"] = torch.empty(B, dtype=torch.float32, device=self.device)
             ws["grad_u"] = torch.empty(B, H, self.m, dtype=torch.float32, device=self.device)
             ws["grad_x0"] = torch.empty(B, self.n, dtype=torch.float32, device=self.device)
-        integ = self._integ(integrator)
         st = self._stream()
+        stash = self._p(ws["stash"])
         rc = self.lib.phnn_rollout_fwd(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), integ, float(dt),
-                                       self._p(ws["cost"]), self._p(ws["traj"]), st)
+                                       self._p(ws["cost"]), self._p(ws["traj"]), stash, st)
         _check(self.lib, self.h, rc)
         rc = self.lib.phnn_rollout_grad(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), integ, float(dt),
-                                        self._p(ws["traj"]), self._p(ws["grad_u"]),
+                                        self._p(ws["traj"]), stash, self._p(ws["grad_u"]),
                                         self._p(ws["grad_x0"]) if want_grad_x0 else None, st)
         _check(self.lib, self.h, rc)
         if want_grad_x0:
@@ -157,8 +169,8 @@ class RolloutEngine:
         gu = torch.empty(B, H, self.m, dtype=torch.float32, device=self.device)
         gx = torch.empty(B, self.n, dtype=torch.float32, device=self.device)
         rc = self.lib.phnn_rollout_vjp(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), self._integ(integrator),
-                                       float(dt), self._p(traj), self._p(tb), self._p(cb), self._p(gu), self._p(gx),
-                                       self._stream())
+                                       float(dt), self._p(traj), None, self._p(tb), self._p(cb), self._p(gu),
+                                       self._p(gx), self._stream())
         _check(self.lib, self.h, rc)
         return gu, gx
 
