@@ -151,14 +151,26 @@ def main():
         flop_job = B * H * stages * (FLOP_FWD + FLOP_VJP)
         bytes_k2 = B * (4 * (n + 2 * H) + 4)  # 4(n + 2 H m) + 4 per rollout with gradient
         ach = flop_k2 / (k2_ms * 1e-3)
+        # HBM bytes per K2 launch from the PMC counters: measured in separate rocprofv3 --pmc passes of this same
+        # command (profiles/traffic_measured.json), reported only for the configuration it was measured on
+        traffic = None
+        mode = "stash" if ws_stash is not None else "recompute"
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic_measured.json")) as f:
+                tm = json.load(f)
+            traffic = tm.get(f"{args.model}:{args.integrator}:B{B}:H{H}:{mode}", {}).get("K2", {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         roof = {
             "bound": "mfma", "kernel": "k_rollout_grad", "achieved": round(ach / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per K2 launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
             "launch_ms": round(k2_ms, 4), "k1_launch_ms": round(k1_ms, 4),
             "job_tflops": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / 1e12, 3),
             "job_frac": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / PEAK_F32_MFMA, 4),
-            "hbm_achieved_GBps": round(bytes_k2 / (k2_ms * 1e-3) / 1e9, 3),
-            "hbm_frac": round(bytes_k2 / (k2_ms * 1e-3) / PEAK_HBM, 6),
+            "hbm_algorithmic_GBps": round(bytes_k2 / (k2_ms * 1e-3) / 1e9, 3),
+            "hbm_algorithmic_frac": round(bytes_k2 / (k2_ms * 1e-3) / PEAK_HBM, 6),
+            "hbm_traffic_frac": None if traffic is None else round(traffic / (k2_ms * 1e-3) / PEAK_HBM, 4),
         }
         cpu = None
         if not args.no_cpu_baseline and world == 1:

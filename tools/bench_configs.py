@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configurations (2, 3, 5) on one GPU; bench.py carries the headline
+configuration (4, per GPU).  Prints one JSON line per configuration.  Run on the GPU box:
+    python tools/bench_configs.py
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phnn_mpc_amd import _capi  # noqa: E402
+from phnn_mpc_amd.engine import RolloutEngine  # noqa: E402
+from phnn_mpc_amd.solver import shooting_solve  # noqa: E402
+
+
+def weights(name):
+    with np.load(os.path.join(ROOT, "tests", "golden", f"weights_{name}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def inputs(n, B, H, amp):
+    rx, ru = np.random.default_rng(1234), np.random.default_rng(5678)
+    scale = np.array([1.0, 0.3, 0.5, 0.5]) if n == 4 else np.array([np.pi, 1.0])
+    return ((rx.uniform(-1, 1, size=(B, n)) * scale).astype(np.float32), ru.uniform(-amp, amp, size=(B, H, 1)).astype(np.float32))
+
+
+def timed(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps
+
+
+def main():
+    dev = "cuda:0"
+    cart = _capi.make_cost(4, 1, [10.0, 200.0, 1.0, 10.0], [0.01], None, -15.0, 15.0)
+    pend = _capi.make_cost(2, 1, [10.0, 1.0], [0.01], None, -2.0, 2.0)
+    out = []
+    # config 2: canonical, H=50, B=4096, forward kernel only
+    eng = RolloutEngine(weights("canonical_cartpole"), dev)
+    x0, U = [torch.tensor(a, device=dev) for a in inputs(4, 4096, 50, 5.0)]
+    for integ in ("euler", "rk4"):
+        t = timed(lambda: eng.rollout_cost(x0, U, cart, integ, 0.02), reps=20)
+        out.append({"config": f"2: canonical cart-pole, {integ}, H=50, B=4096, K1 only", "ms": round(t * 1e3, 4),
+                    "rollouts_per_s": round(4096 / t, 1)})
+    # config 3: pHNN, H=100, B=65536, 20 Adam iterations (K1+K2+K3 each)
+    eng = RolloutEngine(weights("phnn_cartpole"), dev)
+    x0, U = [torch.tensor(a, device=dev) for a in inputs(4, 65536, 100, 5.0)]
+    U0 = torch.zeros_like(U)
+    t = timed(lambda: shooting_solve(eng, x0, U0, cart, "euler", 0.02, 0.015, 20, track_best=True, u_min=-15.0,
+                                     u_max=15.0, record_costs=False), reps=2, warm=1)
+    out.append({"config": "3: pHNN cart-pole, euler, H=100, B=65536, 20 Adam iterations (K1+K2+K3)",
+                "ms": round(t * 1e3, 3), "rollouts_grads_per_s": round(65536 * 20 / t, 1)})
+    # config 5: ODEFunc(2,1), classic RK4, H=200, B=65536
+    eng = RolloutEngine(weights("odefunc_pendulum"), dev)
+    x0, U = [torch.tensor(a, device=dev) for a in inputs(2, 65536, 200, 2.0)]
+    t = timed(lambda: eng.rollout_cost(x0, U, pend, "rk4", 0.05), reps=3, warm=1)
+    out.append({"config": "5: ODEFunc(2,1), rk4, H=200, B=65536, K1 only", "ms": round(t * 1e3, 3),
+                "rollouts_per_s": round(65536 / t, 1)})
+    ws = {}
+    t = timed(lambda: eng.rollout_cost_grad(x0, U, pend, "rk4", 0.05, workspace=ws), reps=2, warm=1)
+    out.append({"config": "5: ODEFunc(2,1), rk4, H=200, B=65536, K1+K2", "ms": round(t * 1e3, 3),
+                "rollouts_grads_per_s": round(65536 / t, 1)})
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()
