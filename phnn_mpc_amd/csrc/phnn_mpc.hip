@@ -445,8 +445,8 @@ int phnn_destroy(phnn_handle* h) {
 int phnn_model_forward(phnn_handle* h, const float* x_dev, const float* u_dev, int64_t B, float* dx_dev, float* H_dev,
                        void* stream) {
   if (!h) return PHNN_ERR_INVALID_ARG;
-  if (!x_dev || !u_dev || !dx_dev || B < 0) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
   if (B == 0) return PHNN_OK;
+  if (!x_dev || !u_dev || !dx_dev || B < 0) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
   if (int rc = check_device(h)) return rc;
   PointParams p{h->d_img, x_dev, u_dev, nullptr, dx_dev, H_dev, (long long)B};
   return launch(h, h->ks.mfwd, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
@@ -455,9 +455,9 @@ int phnn_model_forward(phnn_handle* h, const float* x_dev, const float* u_dev, i
 int phnn_model_vjp(phnn_handle* h, const float* x_dev, const float* u_dev, const float* lam_dev, int64_t B,
                    float* xbar_dev, float* ubar_dev, void* stream) {
   if (!h) return PHNN_ERR_INVALID_ARG;
+  if (B == 0) return PHNN_OK;
   if (!x_dev || !u_dev || !lam_dev || !xbar_dev || !ubar_dev || B < 0)
     return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
-  if (B == 0) return PHNN_OK;
   if (int rc = check_device(h)) return rc;
   PointParams p{h->d_img, x_dev, u_dev, lam_dev, xbar_dev, ubar_dev, (long long)B};
   return launch(h, h->ks.mvjp, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
@@ -465,7 +465,8 @@ int phnn_model_vjp(phnn_handle* h, const float* x_dev, const float* u_dev, const
 
 static int fill_roll(phnn_handle* h, RollParams* p, const float* x0, const float* u, int64_t B, int32_t H,
                      const phnn_cost* cost, int32_t integ, float dt) {
-  if (!x0 || !u || B < 0 || H < 1) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor, negative batch or horizon < 1");
+  if (B < 0 || H < 1) return fail(h, PHNN_ERR_INVALID_ARG, "negative batch or horizon < 1");
+  if (B > 0 && (!x0 || !u)) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor");  // an empty batch may carry NULLs
   if (integ != PHNN_INTEG_EULER && integ != PHNN_INTEG_RK4)
     return fail(h, PHNN_ERR_INVALID_ARG, "Unknown integrator");  // src/integrators.py:172,226 raise ValueError
   if (int rc = check_cost(h, cost)) return rc;
@@ -497,8 +498,8 @@ int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   if (!h) return PHNN_ERR_INVALID_ARG;
   RollParams p;
   if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
-  if (!cost_dev) return fail(h, PHNN_ERR_INVALID_ARG, "cost_dev is NULL");
   if (B == 0) return PHNN_OK;
+  if (!cost_dev) return fail(h, PHNN_ERR_INVALID_ARG, "cost_dev is NULL");
   if (int rc = check_device(h)) return rc;
   p.cost = cost_dev;
   p.traj = traj_dev;
@@ -522,8 +523,8 @@ int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   if (!h) return PHNN_ERR_INVALID_ARG;
   RollParams p;
   if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
-  if (!traj_dev || !grad_u_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev / grad_u_dev is NULL");
   if (B == 0) return PHNN_OK;
+  if (!traj_dev || !grad_u_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev / grad_u_dev is NULL");
   if (int rc = check_device(h)) return rc;
   p.traj_in = traj_dev;
   p.traj_bar = traj_bar_dev;

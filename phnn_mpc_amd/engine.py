@@ -67,8 +67,16 @@ class RolloutEngine:
     def _t(self, a, shape=None):
         t = torch.as_tensor(a, dtype=torch.float32, device=self.device)
         if shape is not None:
+            if t.numel() == 0:  # an empty batch: -1 is ambiguous for reshape
+                shape = tuple(0 if d == -1 else d for d in shape)
             t = t.reshape(shape)
         return t.contiguous()
+
+    def _controls(self, u, B):
+        """(B,H,m) view of the controls; H is read from a 3-D input so that B = 0 keeps its horizon."""
+        u = self._t(u)
+        H = u.shape[1] if u.dim() == 3 else (u.numel() // max(B * self.m, 1))
+        return u.reshape(B, H, self.m), H
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -111,8 +119,7 @@ class RolloutEngine:
         """K1.  x0 (B,n), u (B,H,m) -> cost (B) [, traj (B,H+1,n)]."""
         x0 = self._t(x0, (-1, self.n))
         B = x0.shape[0]
-        u = self._t(u).reshape(B, -1, self.m)
-        H = u.shape[1]
+        u, H = self._controls(u, B)
         c = torch.empty(B, dtype=torch.float32, device=self.device)
         traj = traj_out
         if traj is None and want_traj:
@@ -130,8 +137,7 @@ class RolloutEngine:
         calls to avoid re-allocating the trajectory / outputs."""
         x0 = self._t(x0, (-1, self.n))
         B = x0.shape[0]
-        u = self._t(u).reshape(B, -1, self.m)
-        H = u.shape[1]
+        u, H = self._controls(u, B)
         ws = workspace if workspace is not None else {}
         integ = self._integ(integrator)
         key = (B, H, integ)
@@ -161,8 +167,7 @@ class RolloutEngine:
         """General reverse pass: cotangents on the trajectory (B,H+1,n) and/or the cost (B) -> (grad_u, grad_x0)."""
         x0 = self._t(x0, (-1, self.n))
         B = x0.shape[0]
-        u = self._t(u).reshape(B, -1, self.m)
-        H = u.shape[1]
+        u, H = self._controls(u, B)
         traj = self._t(traj, (B, H + 1, self.n))
         tb = self._t(traj_bar, (B, H + 1, self.n)) if traj_bar is not None else None
         cb = self._t(cost_bar, (B,)) if cost_bar is not None else None

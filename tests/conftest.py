@@ -11,6 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # build the native pieces when a fresh checkout has not run __graft_entry__.build() yet (hipcc cross-compiles
+    # without a GPU; on the GPU box the prebuilt .so files travel with the snapshot)
+    import subprocess
+    lib = os.path.join(ROOT, "phnn_mpc_amd", "csrc", "libphnn_mpc.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.check_call(["make", "-C", os.path.dirname(lib), "-s"])
 
 
 @pytest.fixture(scope="session")

@@ -208,3 +208,44 @@ def test_full_size_properties(torch):
     assert np.allclose(c[idx], ref["cost"], rtol=1e-5)
     gmax = np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True)
     assert np.all(np.abs(gu[idx] - ref["grad_u"]) <= 1e-4 * gmax)
+
+
+def test_edge_sizes(torch):
+    """Empty batch, one-step horizon, a batch of one: shapes and values."""
+    from phnn_mpc_amd.engine import RolloutEngine
+    g = ol.load_golden("phnn_cartpole")
+    w = ol.load_weights("phnn_cartpole")
+    eng, m64 = RolloutEngine(w), ol.OracleModel(w, "f64")
+    cost = ol.cost_from_golden(g)
+    c, gu = eng.rollout_cost_grad(np.zeros((0, 4), np.float32), np.zeros((0, 7, 1), np.float32), cost, "euler", 0.02)
+    assert c.shape == (0,) and gu.shape == (0, 7, 1)
+    dx, H = eng.forward(np.zeros((0, 4), np.float32), np.zeros((0, 1), np.float32))
+    assert dx.shape == (0, 4) and H.shape == (0,)
+    x0, U = g["fwd_x"][:3], g["fwd_u"][:3, None, :]
+    for integ in ("euler", "rk4"):
+        ref = m64.rollout(x0, U, cost, integ, 0.02)
+        c, gu, gx = eng.rollout_cost_grad(x0, U, cost, integ, 0.02, want_grad_x0=True)
+        assert np.allclose(npy(c), ref["cost"], rtol=1e-5)
+        assert np.allclose(npy(gu), ref["grad_u"], rtol=1e-4, atol=1e-5 * np.abs(ref["grad_u"]).max())
+        assert np.allclose(npy(gx), ref["grad_x0"], rtol=1e-4, atol=1e-5 * np.abs(ref["grad_x0"]).max())
+
+
+def test_million_rollouts_properties(torch):
+    """BASELINE config 4's global batch (B = 2^20, H = 50) on one GPU: finite, slice-consistent with small runs."""
+    from phnn_mpc_amd.engine import RolloutEngine
+    g = ol.load_golden("phnn_cartpole")
+    eng = RolloutEngine(ol.load_weights("phnn_cartpole"))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    B, H = 1 << 20, 50
+    x0 = (torch.rand(B, 4, device="cuda", generator=gen) * 2 - 1) * torch.tensor([1.0, 0.3, 0.5, 0.5], device="cuda")
+    U = (torch.rand(B, H, 1, device="cuda", generator=gen) * 2 - 1) * 5.0
+    cost = ol.cost_from_golden(g)
+    ws = {}
+    c, gu = eng.rollout_cost_grad(x0, U, cost, "euler", 0.02, workspace=ws)
+    assert bool(torch.isfinite(c).all()) and bool(torch.isfinite(gu).all())
+    for lo in (0, 524288 - 100, B - 300):
+        c2, g2 = eng.rollout_cost_grad(x0[lo:lo + 300], U[lo:lo + 300], cost, "euler", 0.02)
+        assert torch.equal(c2, c[lo:lo + 300]) and torch.equal(g2, gu[lo:lo + 300])
+    idx = torch.tensor([3, 77777, 555555, B - 1], device="cuda")
+    ref = ol.OracleModel(ol.load_weights("phnn_cartpole"), "f64").rollout(npy(x0[idx]), npy(U[idx]), cost, "euler", 0.02)
+    assert np.allclose(npy(c[idx]), ref["cost"], rtol=1e-5)
