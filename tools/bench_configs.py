@@ -45,6 +45,21 @@ def main():
     cart = _capi.make_cost(4, 1, [10.0, 200.0, 1.0, 10.0], [0.01], None, -15.0, 15.0)
     pend = _capi.make_cost(2, 1, [10.0, 1.0], [0.01], None, -2.0, 2.0)
     out = []
+    # config 1 (plumbing): MPCController.compute_control, pHNN, H=20, 30 Adam iterations, ONE plant, and 4096 plants
+    import yaml
+    from phnn_mpc_amd.models import pHNN
+    from phnn_mpc_amd.mpc_controller import create_mpc_from_config
+    cfgp = os.path.join(ROOT, "configs", "cartpole_mpc.yaml")
+    m = pHNN(cfgp)
+    m.load_state_dict({k: torch.tensor(v) for k, v in weights("phnn_cartpole").items()})
+    ctl = create_mpc_from_config(m, yaml.safe_load(open(cfgp)))
+    st = np.array([0.0, 0.1, 0.0, 0.0], np.float32)
+    t = timed(lambda: ctl.compute_control(st), reps=10, warm=2)
+    out.append({"config": "1: MPCController.compute_control, pHNN, H=20, 30 Adam iterations, B=1", "ms": round(t * 1e3, 3)})
+    S = np.tile(st, (4096, 1)) + np.random.default_rng(0).normal(size=(4096, 4)).astype(np.float32) * 0.05
+    t = timed(lambda: ctl.compute_control_batch(S), reps=5, warm=1)
+    out.append({"config": "1b: compute_control_batch, same settings, 4096 plants at once", "ms": round(t * 1e3, 3),
+                "controls_per_s": round(4096 / t, 1)})
     # config 2: canonical, H=50, B=4096, forward kernel only
     eng = RolloutEngine(weights("canonical_cartpole"), dev)
     x0, U = [torch.tensor(a, device=dev) for a in inputs(4, 4096, 50, 5.0)]
