@@ -19,6 +19,8 @@ Vector sets:
   G7 pendulum 10-step rollouts               golden_phnn_pendulum.npz  g7_*
   G8 dataset windows                         golden_dataset_windows.npz
   G9 soft state barrier (MPCController x_min/x_max) golden_controllers.npz  bar_*
+  G10 reverse pass with trajectory + cost cotangents golden_<model>.npz  tvjp_*
+  G11 the NumPy plant CartPoleSimulator.step         golden_controllers.npz  plant_*
 Each quantity is stored twice: *_f64 from the reference cast to double, *_f32 from the
 reference as shipped (float32, torch CPU).
 """
@@ -286,6 +288,25 @@ def main():
     ctl["bar_xmin"], ctl["bar_xmax"], ctl["bar_u"] = np.asarray(xmin), np.asarray(xmax), ub
     ctl["bar_cost"], ctl["bar_grad"], ctl["bar_states"] = np.float32(cost.item()), ubt.grad.numpy().copy(), st.detach().numpy()
     ctl["bar_u0_after5"] = np.asarray(cb.compute_control(x_init.copy()))
+    # G11: the reference plant (src/cartpole_simulator.py:63-112), 3 plants x 60 steps of seeded forces
+    from cartpole_simulator import CartPoleSimulator
+    rngp = np.random.default_rng(12)
+    init = rngp.uniform(-1, 1, size=(3, 4)) * np.array([0.5, 0.1, 0.3, 0.3])
+    forces = rngp.uniform(-15, 15, size=(60, 3))
+    forces[:, 2] = 14.0  # drives plant 2 over the termination limits
+    traj, dones = [], []
+    for b in range(3):
+        sim = CartPoleSimulator(dt=0.02)
+        sim.reset(init[b])
+        tb, db = [init[b].copy()], []
+        for t in range(60):
+            s_, d_ = sim.step(np.array([forces[t, b]]))
+            tb.append(s_)
+            db.append(d_)
+        traj.append(np.stack(tb))
+        dones.append(np.array(db))
+    ctl["plant_init"], ctl["plant_forces"] = init, forces
+    ctl["plant_states"], ctl["plant_done"] = np.stack(traj, axis=1), np.stack(dones, axis=1)
     np.savez(os.path.join(OUT, "golden_controllers.npz"), **ctl)
 
     # ------------------------------------------------------------------ G8 dataset windows

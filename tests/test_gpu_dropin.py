@@ -249,3 +249,22 @@ def test_million_rollouts_properties(torch):
     idx = torch.tensor([3, 77777, 555555, B - 1], device="cuda")
     ref = ol.OracleModel(ol.load_weights("phnn_cartpole"), "f64").rollout(npy(x0[idx]), npy(U[idx]), cost, "euler", 0.02)
     assert np.allclose(npy(c[idx]), ref["cost"], rtol=1e-5)
+
+
+def test_batched_closed_loop_on_gpu(torch):
+    """Rows f1/f3: 64 plants driven at once (one batched solve per control step) == plants driven one at a time."""
+    from phnn_mpc_amd.closed_loop import BatchedCartPole, run_mpc_batch
+    from phnn_mpc_amd.models import pHNN_Canonical
+    from phnn_mpc_amd.mpc_controller_canonical import create_mpc_controller
+    cfg = yaml.safe_load(open(CFG))
+    c = create_mpc_controller(_load(pHNN_Canonical, CFG, "canonical_cartpole", torch), cfg)
+    c.optimizer_steps = 8
+    rng = np.random.default_rng(6)
+    X0 = rng.uniform(-1, 1, size=(64, 4)) * [0.2, 0.08, 0.1, 0.1]
+    out = run_mpc_batch(BatchedCartPole(0.02), c, X0, 6)
+    assert np.isfinite(out["states"]).all() and out["controls"].shape == (6, 64, 1)
+    assert np.all(np.abs(out["controls"]) <= 15.0)
+    for b in (0, 63):
+        one = run_mpc_batch(BatchedCartPole(0.02), c, X0[b:b + 1], 6)
+        assert np.array_equal(one["controls"][:, 0], out["controls"][:, b])
+        assert np.array_equal(one["states"][:, 0], out["states"][:, b])

@@ -236,3 +236,47 @@ def test_batched_solve_equals_per_sample_solves():
     for b in range(5):
         u1, info = c.control(X[b])
         assert np.array_equal(u1, ub[b]) and np.array_equal(info["u_sequence"], seq[b])
+
+
+# ----------------------------------------------------------------------------- closed loop (rows f1 / f3)
+def test_batched_plant_matches_reference_simulator_g11(ctl):
+    from phnn_mpc_amd.closed_loop import BatchedCartPole
+    sim = BatchedCartPole(dt=0.02)
+    x = sim.reset(ctl["plant_init"])
+    assert np.array_equal(x, ctl["plant_init"])
+    for t in range(60):
+        x, done = sim.step(ctl["plant_forces"][t])
+        assert np.allclose(x, ctl["plant_states"][t + 1], rtol=0, atol=1e-13)
+        assert np.array_equal(done, ctl["plant_done"][t])
+    assert ctl["plant_done"][-1, 2] and not ctl["plant_done"][0].any()
+
+
+def test_batched_closed_loop_equals_per_plant_loops():
+    """run_mpc_batch (one batched solve per control step) == B separate reference-style loops."""
+    from phnn_mpc_amd.closed_loop import BatchedCartPole, run_mpc_batch, stability_report
+    cfg = yaml.safe_load(open(CFG))
+    rng = np.random.default_rng(4)
+    X0 = rng.uniform(-1, 1, size=(3, 4)) * [0.2, 0.08, 0.1, 0.1]
+    for make in (lambda: create_mpc_controller(_canon_with_oracle(), cfg), lambda: create_mpc_from_config(_phnn_with_oracle(), cfg)):
+        c = make()
+        if hasattr(c, "optimizer_steps"):
+            c.optimizer_steps = 4
+        else:
+            c.max_iterations = 4
+        out = run_mpc_batch(BatchedCartPole(0.02), c, X0, 5)
+        assert out["states"].shape == (6, 3, 4) and out["controls"].shape == (5, 3, 1)
+        for b in range(3):
+            sim = BatchedCartPole(0.02)
+            x = sim.reset(X0[b])[0]
+            u_prev = None
+            for t in range(5):
+                if hasattr(c, "control"):
+                    u, info = c.control(x.astype(np.float32), u_prev)
+                    u_prev = info["u_sequence"]
+                else:
+                    u = c.compute_control(x.astype(np.float32))
+                assert np.array_equal(np.asarray(u, np.float64).reshape(-1), out["controls"][t, b])
+                x = sim.step(u)[0][0]
+                assert np.array_equal(x, out["states"][t + 1, b])
+    rep = stability_report(out["states"], [0, 0, 0, 0], cfg["stability"]["tolerance"], cfg["stability"]["min_duration"], 0.02)
+    assert rep["stable"].shape == (3,) and rep["longest_run_s"].shape == (3,)
