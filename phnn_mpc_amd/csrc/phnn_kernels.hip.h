@@ -170,6 +170,157 @@ DEV void sq_bwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
       for (int nt = 0; nt < TO; ++nt) o.v[nt] = mfma(base[(16 * t + r) * LD + 16 * nt], in.v[t][r], o.v[nt]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3 products on the matrix pipe.  f32-input MFMA shares the vector ALUs with VALU; the
+// bf16 MFMA v_mfma_f32_16x16x32_bf16 runs on the separate matrix pipe (19 cycles for 8x the FLOPs of a
+// 32-cycle f32 MFMA, measured by tools/probe_bf16_split.hip) and co-executes with VALU.  Each f32 operand is
+// split exactly into three bf16 pieces x = h + m + l (8+8+8 significant bits); the six products
+// Wh*xh, Wh*xm, Wm*xh, Wm*xm, Wh*xl, Wl*xh, accumulated in f32 inside the MFMA smallest first, reproduce the
+// f32 product to better than the f32 fma chain does (probe on hardware: max error / sum|w||x| 8.9e-8 vs 1.3e-7).
+// Operand registers: for k-step s (32 units = accumulator tiles 2s and 2s+1) lane (i,q) packs its 8 values
+// [tile 2s regs 0..3, tile 2s+1 regs 0..3] as the 8 bf16 of its B fragment, i.e. k-slot 8q+j <-> unit
+// 32s + (j<4 ? 4q+j : 16+4q+j-4); the weight images are stored with the same permutation of their columns.
+// ------------------------------------------------------------------------------------------------
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+DEV unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: round-to-nearest-even, a -> low half
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// Priority: low while a wave streams bf16 MFMAs, higher otherwise, so the SIMD partner's VALU instructions take
+// the issue slots the MFMA stream leaves (arbitration is priority, then age).  Worth +2 % on the bench workload;
+// tools/probe_coexec.hip shows why it cannot be more: on this part an MFMA stream of one wave (bf16 or f32, either
+// shape) hides only ~20 % of its time under the partner wave's VALU work -- matrix and vector time nearly add.
+DEV void matrix_phase_begin() {
+#ifndef PHNN_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+DEV void matrix_phase_end() {
+#ifndef PHNN_NO_SETPRIO
+  __builtin_amdgcn_s_setprio(2);
+#endif
+}
+
+template <int T>
+struct Split3 {  // three bf16 pieces of an activation vector, as MFMA B fragments per 32-unit k-step
+  bf16x8 h[T / 2], m[T / 2], l[T / 2];
+};
+
+template <int T>
+DEV void split_act(const Act<T>& a, Split3<T>& o) {
+#pragma unroll
+  for (int s = 0; s < T / 2; ++s) {
+    u32x4 H, M, Lo;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float x0 = a.v[2 * s + (p >> 1)][2 * (p & 1)], x1 = a.v[2 * s + (p >> 1)][2 * (p & 1) + 1];
+      unsigned hb = pk_bf16(x0, x1);
+      float r0 = x0 - __builtin_bit_cast(float, hb << 16), r1 = x1 - __builtin_bit_cast(float, hb & 0xffff0000u);
+      unsigned mb = pk_bf16(r0, r1);
+      float t0 = r0 - __builtin_bit_cast(float, mb << 16), t1 = r1 - __builtin_bit_cast(float, mb & 0xffff0000u);
+      H[p] = hb;
+      M[p] = mb;
+      Lo[p] = pk_bf16(t0, t1);
+    }
+    o.h[s] = __builtin_bit_cast(bf16x8, H);
+    o.m[s] = __builtin_bit_cast(bf16x8, M);
+    o.l[s] = __builtin_bit_cast(bf16x8, Lo);
+  }
+}
+
+// bf16 weight image: 3 parts [HID rows][RS bf16], RS = HID + 16 (288 B rows at HID = 128: conflict-free
+// ds_read_b128 row reads, 2-way ds_read_b64_tr_b16 transposed reads), columns in k-slot order.
+template <int HID>
+struct BfImg {
+  static constexpr int RS = HID + 16;            // bf16 elements per row
+  static constexpr int PART = HID * RS * 2;      // bytes per part
+  static constexpr int FLOATS = 3 * PART / 4;    // size in floats
+};
+
+// the six products of one k-step for two output tiles, smallest terms first; the two tiles alternate so that
+// dependent MFMAs are two issue slots apart
+DEV void mfma6x2(f32x4& o0, f32x4& o1, const bf16x8 (&a)[2][3], bf16x8 xh, bf16x8 xm, bf16x8 xl) {
+  o0 = mfma_bf(a[0][2], xh, o0);
+  o1 = mfma_bf(a[1][2], xh, o1);
+  o0 = mfma_bf(a[0][0], xl, o0);
+  o1 = mfma_bf(a[1][0], xl, o1);
+  o0 = mfma_bf(a[0][1], xm, o0);
+  o1 = mfma_bf(a[1][1], xm, o1);
+  o0 = mfma_bf(a[0][1], xh, o0);
+  o1 = mfma_bf(a[1][1], xh, o1);
+  o0 = mfma_bf(a[0][0], xm, o0);
+  o1 = mfma_bf(a[1][0], xm, o1);
+  o0 = mfma_bf(a[0][0], xh, o0);
+  o1 = mfma_bf(a[1][0], xh, o1);
+}
+
+// o += W * in  (rows of W on lanes; one ds_read_b128 per part, tile and k-step).
+// (Measured and not kept: k-step-outer order with explicitly double-buffered weight fragments behind
+// sched_barrier -- the LDS latency was already covered by the partner wave: K1 -0.4 %, K2 +6 %.)
+template <int T>
+DEV void sq_fwd_bf(Act<T>& o, const float* Wimg, Lane ln, const Split3<T>& in) {
+  using I = BfImg<16 * T>;
+  keep_lds_reads_local();
+  matrix_phase_begin();
+  const char* base = reinterpret_cast<const char*>(Wimg) + ln.i * (I::RS * 2) + ln.q * 16;
+#pragma unroll
+  for (int n0 = 0; n0 < T; n0 += 2) {
+#pragma unroll
+    for (int s = 0; s < T / 2; ++s) {
+      bf16x8 a[2][3];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[g][p] = *reinterpret_cast<const bf16x8*>(base + p * I::PART + (n0 + g) * 16 * (I::RS * 2) + s * 64);
+      mfma6x2(o.v[n0], o.v[n0 + 1], a, in.h[s], in.m[s], in.l[s]);
+    }
+  }
+  matrix_phase_end();
+}
+
+// o += W^T * in from the SAME image: the A fragment of (output tile nt, k-step s) is 8 rows x 1 column per lane,
+// fetched with two ds_read_b64_tr_b16 (each: 4 rows x 16 columns per 16-lane group, delivered column-major).
+// Lane (q, 4a+pp) supplies the address of row 32s+4q+a (+16 for the second read), k-slot columns
+// 32(nt>>1)+8pp+4(nt&1) .. +3; lane i of the group receives the column of unit 16nt+i.  EXEC is all ones here.
+template <int T>
+DEV void sq_bwd_bf(Act<T>& o, const float* Wimg, Lane ln, const Split3<T>& in) {
+  using I = BfImg<16 * T>;
+  keep_lds_reads_local();
+  matrix_phase_begin();
+  typedef bf16x4 __attribute__((address_space(3))) * lds_bf4;
+  typedef char __attribute__((address_space(3))) * lds_cp;
+  const int a4 = (ln.lane & 15) >> 2, pp = ln.lane & 3;
+  lds_cp base = (lds_cp) const_cast<char*>(reinterpret_cast<const char*>(Wimg)) + (4 * ln.q + a4) * (I::RS * 2) + 16 * pp;
+#pragma unroll
+  for (int n0 = 0; n0 < T; n0 += 2) {
+#pragma unroll
+    for (int s = 0; s < T / 2; ++s) {
+      bf16x8 a[2][3];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int nt = n0 + g;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          lds_cp off = base + p * I::PART + 32 * s * (I::RS * 2) + (64 * (nt >> 1) + 8 * (nt & 1));
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4)off);
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4)(off + 16 * (I::RS * 2)));
+          a[g][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+      mfma6x2(o.v[n0], o.v[n0 + 1], a, in.h[s], in.m[s], in.l[s]);
+    }
+  }
+  matrix_phase_end();
+}
+
 // 16*TI units -> 4 outputs, every lane receives all 4 (row 4q+r of the MFMA tile carries output r).
 // Wt is [4][LR], LR = 16*TI + 8, row c = weights of output c.
 template <int TI>
@@ -229,11 +380,11 @@ DEV float reduce_q(float v) {  // sum over the 4 lanes (q = 0..3) of a rollout
 // ------------------------------------------------------------------------------------------------
 // LDS image layouts (offsets in floats; every section size is a multiple of 4 floats)
 // ------------------------------------------------------------------------------------------------
-template <int HID>
+template <int HID, bool BF = false>
 struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int T = HID / 16, LD = HID + 4, LR = HID + 8;
-  static constexpr int oW2 = 0;                  // [HID][LD]
-  static constexpr int oW1f = oW2 + HID * LD;    // [T][64] fragment image of W1
+  static constexpr int oW2 = 0;                  // f32: [HID][LD];  BF: bf16x3 image (BfImg<HID>)
+  static constexpr int oW1f = oW2 + (BF ? BfImg<HID>::FLOATS : HID * LD);  // [T][64] fragment image of W1
   static constexpr int oB1 = oW1f + T * 64;      // [HID]
   static constexpr int oB2 = oB1 + HID;          // [HID]
   static constexpr int oW3 = oB2 + HID;          // [HID]
@@ -261,15 +412,21 @@ struct HTape {
   Act<HID / 16> a1, a2, q1;  // activations, and q1 = W2^T g2 (before the (1-a1^2) factor)
 };
 
-template <int HID, bool WANT_H>
+template <int HID, bool WANT_H, bool BF = false>
 DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hval) {
-  using Y = LayH2<HID>;
+  using Y = LayH2<HID, BF>;
   constexpr int T = Y::T;
   load_vec<T>(tp.a1, L + Y::oB1, ln);
   in_layer<T>(tp.a1, L + Y::oW1f, ln, sel4(z, ln.q));
   tanh_act<T>(tp.a1);
   load_vec<T>(tp.a2, L + Y::oB2, ln);
-  sq_fwd<T, T>(tp.a2, L + Y::oW2, ln, tp.a1);
+  if (BF) {
+    Split3<T> sp;
+    split_act<T>(tp.a1, sp);
+    sq_fwd_bf<T>(tp.a2, L + Y::oW2, ln, sp);
+  } else {
+    sq_fwd<T, T>(tp.a2, L + Y::oW2, ln, tp.a1);
+  }
   tanh_act<T>(tp.a2);
   Act<T> g;
   float s = 0.f;
@@ -285,7 +442,13 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
   }
   if (WANT_H) Hval = reduce_q(s) + L[Y::oB3];
   zero_act<T>(tp.q1);
-  sq_bwd<T, T>(tp.q1, L + Y::oW2, ln, g);
+  if (BF) {
+    Split3<T> sp;
+    split_act<T>(g, sp);
+    sq_bwd_bf<T>(tp.q1, L + Y::oW2, ln, sp);
+  } else {
+    sq_bwd<T, T>(tp.q1, L + Y::oW2, ln, g);
+  }
 #pragma unroll
   for (int t = 0; t < T; ++t) g.v[t] = tp.q1.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
   return to4_rep<T>(L + Y::oW1T, ln, g);
@@ -293,20 +456,26 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
 
 // Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
 // (q1 is overwritten) to keep the live register set at five activation vectors.
-template <int HID>
+template <int HID, bool BF = false>
 DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
-  using Y = LayH2<HID>;
+  using Y = LayH2<HID, BF>;
   constexpr int T = Y::T;
   Act<T> ad1, w;
   zero_act<T>(ad1);
   in_layer<T>(ad1, L + Y::oW1f, ln, sel4(v, ln.q));
 #pragma unroll
   for (int t = 0; t < T; ++t) ad1.v[t] = (1.0f - tp.a1.v[t] * tp.a1.v[t]) * ad1.v[t];
-  zero_act<T>(w);
-  sq_fwd<T, T>(w, L + Y::oW2, ln, ad1);
-  // second term of gdot1 = qdot1*(1-a1^2) + q1*(-2 a1 adot1): fold it now, adot1 dies here
+  // second term of gdot1 = qdot1*(1-a1^2) + q1*(-2 a1 adot1): fold it now, adot1 dies after the product
 #pragma unroll
   for (int t = 0; t < T; ++t) tp.q1.v[t] = tp.q1.v[t] * (-2.0f * tp.a1.v[t] * ad1.v[t]);
+  zero_act<T>(w);
+  if (BF) {
+    Split3<T> sp;
+    split_act<T>(ad1, sp);
+    sq_fwd_bf<T>(w, L + Y::oW2, ln, sp);
+  } else {
+    sq_fwd<T, T>(w, L + Y::oW2, ln, ad1);
+  }
   keep_lds_reads_local();
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -317,7 +486,13 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   }
   Act<T> qd;
   zero_act<T>(qd);
-  sq_bwd<T, T>(qd, L + Y::oW2, ln, w);
+  if (BF) {
+    Split3<T> sp;
+    split_act<T>(w, sp);
+    sq_bwd_bf<T>(qd, L + Y::oW2, ln, sp);
+  } else {
+    sq_bwd<T, T>(qd, L + Y::oW2, ln, w);
+  }
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     f32x4 a1 = tp.a1.v[t];
@@ -360,12 +535,12 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
 // ------------------------------------------------------------------------------------------------
 // Model: pHNN (src/pHNN.py:52-100)
 // ------------------------------------------------------------------------------------------------
-template <int N_, int HID_, bool FIXG_>
+template <int N_, int HID_, bool FIXG_, bool BF_ = false>
 struct PhnnModel {
   static constexpr int N = N_, HID = HID_, T = HID / 16;
-  static constexpr bool FIXG = FIXG_;
+  static constexpr bool FIXG = FIXG_, BF = BF_;
   static constexpr int oH = 0;
-  static constexpr int oR = oH + LayH2<HID>::SIZE;
+  static constexpr int oR = oH + LayH2<HID, BF>::SIZE;
   static constexpr int oGn = oR + LayH1<HID>::SIZE;
   static constexpr int oJ = oGn + (FIXG ? 0 : LayH1<HID>::SIZE);  // [16] J - J^T, row-major N x N
   static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
@@ -379,7 +554,7 @@ struct PhnnModel {
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H>(L + oH, ln, x, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, BF>(L + oH, ln, x, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a1);
       store_act<T>(stash + T * 256, ln, tp.a2);
@@ -443,7 +618,7 @@ struct PhnnModel {
       load_act<T>(stash + 2 * T * 256, ln, tp.q1);
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
     } else {
-      dH = hnet_grad<HID, false>(L + oH, ln, x, tp, Hdummy);
+      dH = hnet_grad<HID, false, BF>(L + oH, ln, x, tp, Hdummy);
     }
     f32x4 xb = splat4(0.f);
     float S[N][N], Stl[N], StdH[N];
@@ -508,7 +683,7 @@ struct PhnnModel {
       for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[j][k], Stl[k], acc);
       v[j] = acc;
     }
-    xbar = xb + hnet_hvp<HID>(L + oH, ln, tp, v);
+    xbar = xb + hnet_hvp<HID, BF>(L + oH, ln, tp, v);
   }
 };
 
@@ -516,11 +691,12 @@ struct PhnnModel {
 // Model: canonical pHNN with the cart-pole mass matrix (src/pHNN_canonical.py:172-273,
 // src/mass_matrix.py:270-362, src/coordinate_transforms.py:20-130)
 // ------------------------------------------------------------------------------------------------
-template <int HID_>
+template <int HID_, bool BF_ = false>
 struct CanonModel {
   static constexpr int N = 4, HID = HID_, T = HID / 16;
+  static constexpr bool BF = BF_;
   static constexpr int oH = 0;
-  static constexpr int oC = oH + LayH2<HID>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
+  static constexpr int oC = oH + LayH2<HID, BF>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
   static constexpr int IMG = oC + 12;
 
   static constexpr int STASH = 3 * T * 256 + 64;
@@ -534,7 +710,7 @@ struct CanonModel {
     float bc = b * cs;
     f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H>(L + oH, ln, z, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, BF>(L + oH, ln, z, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a1);
       store_act<T>(stash + T * 256, ln, tp.a2);
@@ -567,7 +743,7 @@ struct CanonModel {
       load_act<T>(stash + 2 * T * 256, ln, tp.q1);
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
     } else {
-      dH = hnet_grad<HID, false>(L + oH, ln, z, tp, Hdummy);
+      dH = hnet_grad<HID, false, BF>(L + oH, ln, z, tp, Hdummy);
     }
     float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
     float dp0 = (-dH[0] - Rd2 * dH[2]) + L[oC + 10] * u;
@@ -582,7 +758,7 @@ struct CanonModel {
     float mb11 = lam[1] * z[3] + lam[3] * dp1;
     f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
     ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
-    f32x4 zb = hnet_hvp<HID>(L + oH, ln, tp, v);
+    f32x4 zb = hnet_hvp<HID, BF>(L + oH, ln, tp, v);
     zb[2] += pb0;
     zb[3] += pb1;
     float bcb = zb[2] * y[3] + zb[3] * y[2];
@@ -749,7 +925,6 @@ struct RollParams {
   float* stash;        // K1 -> K2 tape workspace (Euler only) or null: [tile][t][M::STASH] floats
   long long B;
   int H;
-  int stagger;  // waves of the second half of a workgroup start this many s_sleep(127) late (see stagger_waves)
   float dt, half_dt, sixth_dt;
   phnn_cost c;
 };
@@ -770,15 +945,6 @@ DEV void stage_image(float* lds, const float* img) {
   f32x4* dst = reinterpret_cast<f32x4*>(lds);
   for (int k = threadIdx.x; k < IMG / 4; k += blockDim.x) dst[k] = src[k];
   __syncthreads();
-}
-
-// The two waves that share a SIMD (w and w + nwaves/2) run the same program; started together they stay in
-// phase -- both in their MFMA blocks (halving each other's rate), then both in their tanh/VALU blocks (matrix
-// pipe idle).  Starting the second half late by a fraction of a step lets one wave's VALU phases fall under
-// the other's MFMA phases (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
-DEV void stagger_waves(int wave, int nwaves, int sleeps) {
-  if (nwaves >= 2 && wave >= (nwaves + 1) / 2)
-    for (int k = 0; k < sleeps; ++k) __builtin_amdgcn_s_sleep(127);
 }
 
 template <int N>
@@ -819,7 +985,6 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   const bool valid = b < p.B;
   if (!valid) b = p.B - 1;
   const float* L = lds;
-  stagger_waves(wave, nwaves, p.stagger);
   f32x4 x = load_state<N>(p.x0 + b * N);
   const bool writer = valid && ln.q == 0;
   if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1)) * N, x);
@@ -863,7 +1028,6 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   const bool valid = b < p.B;
   if (!valid) b = p.B - 1;
   const float* L = lds;
-  stagger_waves(wave, nwaves, p.stagger);
   const bool writer = valid && ln.q == 0;
   const float* tr = p.traj_in + (b * (p.H + 1)) * N;
   const float* up = p.u + b * p.H;

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -15,7 +16,6 @@
 namespace {
 
 thread_local std::string g_create_error;
-constexpr int kDefaultStagger = 0;
 
 enum Variant {
   V_NONE = 0,
@@ -28,6 +28,8 @@ enum Variant {
   V_ODE_2_128,       // ODEFunc(2,1), hidden [128,128,128]
   V_ODE_2_64,
   V_ODE_3_128,
+  V_PHNN_4_128_FIX_BF,  // same models, 128x128 products as bf16x3 on the matrix pipe (default)
+  V_CANON_128_BF,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -39,6 +41,8 @@ using M_CANON_64 = CanonModel<64>;
 using M_ODE_2_128 = OdeModel<2, 128>;
 using M_ODE_2_64 = OdeModel<2, 64>;
 using M_ODE_3_128 = OdeModel<3, 128>;
+using M_PHNN_4_128_FIX_BF = PhnnModel<4, 128, true, true>;
+using M_CANON_128_BF = CanonModel<128, true>;
 
 struct KernelSet {
   void (*fwd[2])(RollParams);
@@ -80,6 +84,8 @@ bool kernel_set(int v, KernelSet* k) {
     case V_ODE_2_128: *k = make_set<M_ODE_2_128>("odefunc<n=2,hid=128>"); return true;
     case V_ODE_2_64: *k = make_set<M_ODE_2_64>("odefunc<n=2,hid=64>"); return true;
     case V_ODE_3_128: *k = make_set<M_ODE_3_128>("odefunc<n=3,hid=128>"); return true;
+    case V_PHNN_4_128_FIX_BF: *k = make_set<M_PHNN_4_128_FIX_BF>("phnn<n=4,hid=128,fixedG,bf16x3>"); return true;
+    case V_CANON_128_BF: *k = make_set<M_CANON_128_BF>("canonical<hid=128,bf16x3>"); return true;
     default: return false;
   }
 }
@@ -125,6 +131,13 @@ bool same_hidden(const phnn_mlp_shape& s, int depth, int hid) {
   return true;
 }
 
+// PHNN_MATMUL=f32 selects the all-f32-MFMA kernels; default is the bf16x3 split on the matrix pipe where a
+// variant exists (same f32-level accuracy, see tools/probe_bf16_split.hip and DESIGN.md 3.3).
+bool use_bf16x3() {
+  const char* e = getenv("PHNN_MATMUL");
+  return !(e && strcmp(e, "f32") == 0);
+}
+
 int pick_variant(const phnn_desc* d, std::string* why) {
   char buf[256];
   if (d->m != 1) {
@@ -136,7 +149,7 @@ int pick_variant(const phnn_desc* d, std::string* why) {
     int hid = d->h_net.hidden[0];
     bool ok = same_hidden(d->h_net, 2, hid) && same_hidden(d->r_net, 1, hid) &&
               (d->fixed_G || same_hidden(d->g_net, 1, hid));
-    if (ok && d->n == 4 && hid == 128 && d->fixed_G) return V_PHNN_4_128_FIX;
+    if (ok && d->n == 4 && hid == 128 && d->fixed_G) return use_bf16x3() ? V_PHNN_4_128_FIX_BF : V_PHNN_4_128_FIX;
     if (ok && d->n == 4 && hid == 64 && d->fixed_G) return V_PHNN_4_64_FIX;
     if (ok && d->n == 2 && hid == 64 && !d->fixed_G) return V_PHNN_2_64_GNET;
     if (ok && d->n == 2 && hid == 64 && d->fixed_G) return V_PHNN_2_64_FIX;
@@ -149,7 +162,7 @@ int pick_variant(const phnn_desc* d, std::string* why) {
   }
   if (d->kind == PHNN_MODEL_CANONICAL) {
     int hid = d->h_net.hidden[0];
-    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 128) return V_CANON_128;
+    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 128) return use_bf16x3() ? V_CANON_128_BF : V_CANON_128;
     if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 64) return V_CANON_64;
     snprintf(buf, sizeof buf, "canonical pHNN n=%d H_net depth %d width %d: no kernel instantiated", d->n,
              d->h_net.depth, hid);
@@ -199,16 +212,51 @@ void pack_cols_as_rows(float* dst, const float* W, int rows, int cols, int ld) {
     for (int c = 0; c < cols; ++c) dst[(size_t)c * ld + r] = W[(size_t)r * cols + c];
 }
 
+uint16_t bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+float bf16_to_f32(uint16_t b) {
+  uint32_t u = ((uint32_t)b) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// W (HID x HID, row-major) -> three bf16 parts [HID][RS] with the columns in k-slot order: position
+// 32s + 8q + j holds unit 32s + (j < 4 ? 4q + j : 16 + 4q + j - 4)  (phnn_kernels.hip.h, "bf16x3 products")
 template <int HID>
+void pack_bf16x3(float* dstf, const float* W) {
+  using I = BfImg<HID>;
+  uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
+  for (int r = 0; r < HID; ++r)
+    for (int pos = 0; pos < HID; ++pos) {
+      int s = pos / 32, w = pos % 32, q = w / 8, j = w % 8;
+      int u = 32 * s + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
+      float x = W[(size_t)r * HID + u];
+      uint16_t h = bf16_rne(x);
+      float r1 = x - bf16_to_f32(h);
+      uint16_t m = bf16_rne(r1);
+      uint16_t l = bf16_rne(r1 - bf16_to_f32(m));
+      size_t at = (size_t)r * I::RS + pos;
+      dst[at] = h;
+      dst[(size_t)I::PART / 2 + at] = m;
+      dst[(size_t)I::PART + at] = l;
+    }
+}
+
+template <int HID, bool BF>
 const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes W1,b1,W2,b2,W3,b3 from p
-  using Y = LayH2<HID>;
+  using Y = LayH2<HID, BF>;
   const float* W1 = p; p += (size_t)HID * nin;
   const float* b1 = p; p += HID;
   const float* W2 = p; p += (size_t)HID * HID;
   const float* b2 = p; p += HID;
   const float* W3 = p; p += HID;
   const float* b3 = p; p += 1;
-  pack_rows(dst + Y::oW2, W2, HID, HID, Y::LD);
+  if (BF) pack_bf16x3<HID>(dst + Y::oW2, W2);
+  else pack_rows(dst + Y::oW2, W2, HID, HID, Y::LD);
   pack_in_frag<HID>(dst + Y::oW1f, W1, nin);
   memcpy(dst + Y::oB1, b1, sizeof(float) * HID);
   memcpy(dst + Y::oB2, b2, sizeof(float) * HID);
@@ -241,7 +289,7 @@ void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
   const float* G = nullptr;
   if (d->fixed_G) { G = p; p += N; }
   p = pack_h1<HID>(img.data() + M::oR, p, N, N * N);
-  p = pack_h2<HID>(img.data() + M::oH, p, N);
+  p = pack_h2<HID, M::BF>(img.data() + M::oH, p, N);
   if (!d->fixed_G) p = pack_h1<HID>(img.data() + M::oGn, p, N, N);
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) img[M::oJ + i * N + j] = J[i * N + j] - J[j * N + i];  // src/pHNN.py:83, no 1/2
@@ -259,7 +307,7 @@ void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
   const float* G = p; p += 4;
   float log_a = p[0], b = p[1], log_c = p[2];
   p += 3;
-  p = pack_h2<HID>(img.data() + M::oH, p, 4);
+  p = pack_h2<HID, M::BF>(img.data() + M::oH, p, 4);
   float* c = img.data() + M::oC;
   c[0] = expf(log_a) + 1e-3f;  // src/mass_matrix.py:286-288
   c[1] = b;
@@ -304,6 +352,8 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_ODE_2_128: pack_ode<M_ODE_2_128>(img, d, blob); break;
     case V_ODE_2_64: pack_ode<M_ODE_2_64>(img, d, blob); break;
     case V_ODE_3_128: pack_ode<M_ODE_3_128>(img, d, blob); break;
+    case V_PHNN_4_128_FIX_BF: pack_phnn<M_PHNN_4_128_FIX_BF>(img, d, blob); break;
+    case V_CANON_128_BF: pack_canon<M_CANON_128_BF>(img, d, blob); break;
     default: break;
   }
 }
@@ -317,7 +367,6 @@ struct phnn_handle {
   KernelSet ks;
   float* d_img;
   int n_cu;
-  int stagger;  // s_sleep(127) count for the late half of each workgroup (tuning knob, env PHNN_STAGGER)
   std::string err;
 };
 
@@ -337,7 +386,7 @@ int hip_fail(phnn_handle* h, hipError_t e, const char* what) {
 // workgroup; fewer waves per workgroup for small batches so the tiles spread over the CUs.
 int pick_waves(long long tiles, int n_cu) {
   int w = kMaxWaves;
-  if (const char* e = getenv("PHNN_MAX_WAVES")) {  // tuning knob
+  if (const char* e = getenv("PHNN_MAX_WAVES")) {  // diagnostic knob: 4 = one wave per SIMD
     int v = atoi(e);
     if (v >= 1 && v <= kMaxWaves) w = v;
   }
@@ -413,8 +462,6 @@ int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_float
   h->device = device;
   h->variant = v;
   kernel_set(v, &h->ks);
-  h->stagger = kDefaultStagger;
-  if (const char* e = getenv("PHNN_STAGGER")) h->stagger = atoi(e);
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device);
   h->n_cu = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -482,7 +529,6 @@ static int fill_roll(phnn_handle* h, RollParams* p, const float* x0, const float
   p->half_dt = (float)(dtd / 2);
   p->sixth_dt = (float)(dtd / 6.0);
   p->c = *cost;
-  p->stagger = h->stagger;
   return PHNN_OK;
 }
 

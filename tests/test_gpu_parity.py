@@ -200,3 +200,32 @@ def test_stash_and_recompute_modes_agree(bundle):
     assert np.all(np.abs(g1 - g2) <= 1e-6 * gmax) and np.allclose(x1, x2, rtol=1e-5, atol=1e-6 * np.abs(x2).max())
     ref = m64.rollout(x0, U, cost, "euler", float(g["dt"]), nthreads=8)
     assert np.all(np.abs(g2 - ref["grad_u"]) <= 1e-4 * np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True))
+
+
+@pytest.mark.parametrize("name", ["phnn_cartpole", "canonical_cartpole"])
+def test_f32_and_bf16x3_matmul_variants(torch_cuda, name):
+    """The 128x128 products run as a 3-way bf16 split on the matrix pipe by default; PHNN_MATMUL=f32 selects the
+    all-f32-MFMA kernels.  Both must sit within the stated tolerances of the float64 oracle."""
+    import os
+    from phnn_mpc_amd.engine import RolloutEngine
+    g, w = ol.load_golden(name), ol.load_weights(name)
+    m64 = ol.OracleModel(w, "f64")
+    rng = np.random.default_rng(31)
+    B, H = 200, 60
+    x0 = (rng.uniform(-1, 1, size=(B, 4)) * [1.0, 0.3, 0.5, 0.5]).astype(np.float32)
+    U = rng.uniform(-17, 17, size=(B, H, 1)).astype(np.float32)
+    cost = ol.cost_from_golden(g)
+    ref = m64.rollout(x0, U, cost, "euler", 0.02, nthreads=8)
+    res = {}
+    for mode in ("bf16x3", "f32"):
+        os.environ["PHNN_MATMUL"] = mode
+        try:
+            eng = RolloutEngine(w)
+        finally:
+            os.environ.pop("PHNN_MATMUL", None)
+        c, gu, gx = eng.rollout_cost_grad(x0, U, cost, "euler", 0.02, want_grad_x0=True)
+        _, tr = eng.rollout_cost(x0, U, cost, "euler", 0.02, want_traj=True)
+        assert_rollout_close(npy(c), npy(tr), npy(gu), npy(gx), ref["cost"], ref["traj"], ref["grad_u"], ref["grad_x0"])
+        res[mode] = (npy(c), npy(gu))
+    assert not np.array_equal(res["f32"][1], res["bf16x3"][1])  # they really are different kernels
+    assert np.allclose(res["f32"][0], res["bf16x3"][0], rtol=2e-6)
