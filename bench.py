@@ -12,10 +12,13 @@ own 65536 rollouts (weak scaling; rollouts are independent).  Rank 0 prints ONE 
 
 Extra objects on the line:
   roofline      for the dominant kernel (K2, k_rollout_grad): algorithmic FLOPs per launch (SURVEY.md 8d:
-                74.2 kFLOP per rollout-step of VJP work; the in-kernel recompute of the forward tape is not
-                counted) / average launch duration measured live with events on the launch stream, against the
-                dense f32 MFMA peak of 157.3 TFLOP/s.  hbm_* fields give the same launch against the 8 TB/s HBM
-                roof from algorithmic bytes, as north_star asks -- the path is not HBM-bound.
+                74.2 kFLOP per rollout-step of VJP work) / average launch duration measured live with events on
+                the launch stream.  Peak: the dense MFMA peak of the matrix dtype divided by the number of split
+                products one f32 product costs (f16x2: 2500/3 TFLOP/s; bf16x3: 2500/6; f32: 157.3); the fraction
+                of the f32 MFMA/vector peak is given next to it (vs_f32_mfma_peak, > 1 means the f32 ALUs could
+                not have done it).  traffic = measured HBM bytes per K2 launch (separate --pmc passes), mostly
+                the K1->K2 activation stash; hbm_* fields compare algorithmic and measured bytes with the 8 TB/s
+                roof, as north_star asks.
   cpu_baseline  the CPU oracle (plain-C port of the reference algorithm, float32, OpenMP over rollouts) timed
                 on this box's host cores on a bounded sample of the same workload.
 """
@@ -33,8 +36,11 @@ sys.path.insert(0, ROOT)
 # algorithmic work per rollout-step, cart-pole pHNN
 FLOP_FWD = 73.0e3  # f(x,u): H_net value+grad, R_net, combine
 FLOP_VJP = 72.7e3 + 1.5e3  # (df/dx)^T lam incl. Hessian-vector product
-PEAK_F32_MFMA = 157.3e12
+PEAK_F32_MFMA = 157.3e12   # dense f32 MFMA = f32 vector peak (MI355X_MICROARCH.md)
+PEAK_16BIT_MFMA = 2.5e15   # dense bf16 / f16 MFMA peak
 PEAK_HBM = 8.0e12
+# matrix instructions issued per f32-equivalent product in each matmul mode
+SPLIT_PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3}
 
 
 def parse():
@@ -161,13 +167,19 @@ def main():
             traffic = tm.get(f"{args.model}:{args.integrator}:B{B}:H{H}:{mode}", {}).get("K2", {}).get("hbm_bytes_per_launch")
         except OSError:
             pass
+        mm = eng.matmul_mode
+        peak = PEAK_F32_MFMA if mm == "f32" else PEAK_16BIT_MFMA / SPLIT_PRODUCTS[mm]
         roof = {
-            "bound": "mfma", "kernel": "k_rollout_grad", "achieved": round(ach / 1e12, 3), "peak": PEAK_F32_MFMA / 1e12,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA, 4), "traffic": traffic,
+            "bound": "mfma", "kernel": "k_rollout_grad", "achieved": round(ach / 1e12, 3), "peak": round(peak / 1e12, 1),
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "peak_basis": ("dense f32 MFMA peak" if mm == "f32" else
+                           f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS[mm]} split products per f32 product ({mm})"),
+            "vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA, 4),
             "traffic_unit": "HBM bytes per K2 launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
             "launch_ms": round(k2_ms, 4), "k1_launch_ms": round(k1_ms, 4),
             "job_tflops": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / 1e12, 3),
-            "job_frac": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / PEAK_F32_MFMA, 4),
+            "job_frac": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / peak, 4),
+            "job_vs_f32_mfma_peak": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / PEAK_F32_MFMA, 4),
             "hbm_algorithmic_GBps": round(bytes_k2 / (k2_ms * 1e-3) / 1e9, 3),
             "hbm_algorithmic_frac": round(bytes_k2 / (k2_ms * 1e-3) / PEAK_HBM, 6),
             "hbm_traffic_frac": None if traffic is None else round(traffic / (k2_ms * 1e-3) / PEAK_HBM, 4),
@@ -183,7 +195,8 @@ def main():
             "config": {"workload": f"{args.model} (seed-0 fixture weights) {args.integrator} H={H} "
                                    f"B={B}/GPU: rollout + stage cost (K1) + control gradient (K2)"
                                    + (" + RCCL all-gather of costs" if world > 1 else ""),
-                       "k2_mode": "stash" if ws_stash is not None else "recompute", "horizon": H, "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"shard{world}"},
+                       "k2_mode": "stash" if ws_stash is not None else "recompute", "matmul": eng.matmul_mode,
+                       "kernel_variant": eng.variant, "horizon": H, "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"shard{world}"},
             "roofline": roof,
         }
         if cpu is not None:

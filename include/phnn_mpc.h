@@ -165,6 +165,11 @@ int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* e
 int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts_per_wg,
                      int32_t* lds_bytes, int32_t* n_workgroups_for_B, int64_t B);
 
+/* Name of the kernel variant serving this handle, e.g. "phnn<n=4,hid=128,fixedG,f16x2>".  The hidden x hidden
+ * products run as all-f32 MFMAs ("f32"), as an exact 3-way bf16 split ("bf16x3") or 2-way f16 split ("f16x2",
+ * default) on the matrix pipe; the environment variable PHNN_MATMUL selects one at phnn_create time. */
+const char* phnn_variant_name(const phnn_handle* h);
+
 /* Library version (major*10000 + minor*100 + patch). */
 int phnn_version(void);
 

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libphnn_mpc.so")
 EXPORTED = [
     "phnn_create", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
     "phnn_model_vjp", "phnn_rollout_fwd", "phnn_workspace_bytes", "phnn_rollout_grad", "phnn_rollout_vjp",
-    "phnn_adam_step", "phnn_kernel_info",
+    "phnn_adam_step", "phnn_kernel_info", "phnn_variant_name",
     "phnn_version",
 ]
 
@@ -139,6 +139,8 @@ def load_library():
     lib.phnn_adam_step.restype = C.c_int
     lib.phnn_kernel_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i64]
     lib.phnn_kernel_info.restype = C.c_int
+    lib.phnn_variant_name.argtypes = [vp]
+    lib.phnn_variant_name.restype = C.c_char_p
     lib.phnn_version.argtypes = []
     lib.phnn_version.restype = C.c_int
     _lib = lib

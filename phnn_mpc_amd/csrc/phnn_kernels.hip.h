@@ -48,6 +48,11 @@ DEV float sel4(f32x4 v, int q) { return q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2
 //   default  : 1 - 2/(1 + 2^(2x*log2 e)), 5 instructions, abs. error <= 2.5e-7 everywhere (relative error
 //              grows towards x = 0 but the absolute error is what propagates through the sums)
 //   -DPHNN_TANH_ACCURATE : odd minimax polynomial below 0.4 (rel. 6e-8) + the same formula above (abs. 1e-7)
+DEV float tanh_scaled(float x, float c) {  // tanh(x * c / (2 log2 e)): the pre-activation carries a power-of-two scale
+  float e = __builtin_amdgcn_exp2f(x * c);
+  return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+
 DEV float tanh_dev(float x) {
 #ifdef PHNN_TANH_ACCURATE
   float ax = __builtin_fabsf(x);
@@ -321,6 +326,113 @@ DEV void sq_bwd_bf(Act<T>& o, const float* Wimg, Lane ln, const Split3<T>& in) {
   matrix_phase_end();
 }
 
+// ------------------------------------------------------------------------------------------------
+// f16x2 products: half the matrix instructions of bf16x3.  x = h + l with h = f16(x), l = f16(x - h) carries 22
+// significant bits; the three products Wh*xh, Wh*xl, Wl*xh on v_mfma_f32_16x16x32_f16 give ~2^-22 relative
+// accuracy per term provided the operands sit in f16's range: weights are stored times a power of two S (largest
+// |w| S in [0.5,1)), tanh outputs and g = w3 (1 - a^2) are O(1) by construction, and the Hessian-vector product is
+// linear in its input vector, which is normalised by a power of two per rollout (hnet_hvp).  All scale factors are
+// powers of two and are folded into constants of the image (bias * S, tanh constant / S, W1^T / S, w3 / S).
+// ------------------------------------------------------------------------------------------------
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+DEV f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+template <int T>
+struct Split2 {
+  f16x8 h[T / 2], l[T / 2];
+};
+
+template <int T>
+DEV void split_act_h(const Act<T>& a, Split2<T>& o) {
+#pragma unroll
+  for (int s = 0; s < T / 2; ++s) {
+    u32x4 H, Lo;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f32x2 x = {a.v[2 * s + (p >> 1)][2 * (p & 1)], a.v[2 * s + (p >> 1)][2 * (p & 1) + 1]};
+      f16x2 hb = __builtin_convertvector(x, f16x2);
+      f32x2 r = x - __builtin_convertvector(hb, f32x2);
+      H[p] = __builtin_bit_cast(unsigned, hb);
+      Lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    }
+    o.h[s] = __builtin_bit_cast(f16x8, H);
+    o.l[s] = __builtin_bit_cast(f16x8, Lo);
+  }
+}
+
+template <int HID>
+struct HfImg {  // 2 parts [HID rows][RS f16], same row stride and column permutation as BfImg
+  static constexpr int RS = HID + 16;
+  static constexpr int PART = HID * RS * 2;
+  static constexpr int FLOATS = 2 * PART / 4;
+};
+
+DEV void mfma3x2(f32x4& o0, f32x4& o1, const f16x8 (&a)[2][2], f16x8 xh, f16x8 xl) {
+  o0 = mfma_h(a[0][1], xh, o0);
+  o1 = mfma_h(a[1][1], xh, o1);
+  o0 = mfma_h(a[0][0], xl, o0);
+  o1 = mfma_h(a[1][0], xl, o1);
+  o0 = mfma_h(a[0][0], xh, o0);
+  o1 = mfma_h(a[1][0], xh, o1);
+}
+
+template <int T>
+DEV void sq_fwd_h(Act<T>& o, const float* Wimg, Lane ln, const Split2<T>& in) {
+  using I = HfImg<16 * T>;
+  keep_lds_reads_local();
+  matrix_phase_begin();
+  const char* base = reinterpret_cast<const char*>(Wimg) + ln.i * (I::RS * 2) + ln.q * 16;
+#pragma unroll
+  for (int n0 = 0; n0 < T; n0 += 2) {
+#pragma unroll
+    for (int s = 0; s < T / 2; ++s) {
+      f16x8 a[2][2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          a[g][p] = *reinterpret_cast<const f16x8*>(base + p * I::PART + (n0 + g) * 16 * (I::RS * 2) + s * 64);
+      mfma3x2(o.v[n0], o.v[n0 + 1], a, in.h[s], in.l[s]);
+    }
+  }
+  matrix_phase_end();
+}
+
+template <int T>
+DEV void sq_bwd_h(Act<T>& o, const float* Wimg, Lane ln, const Split2<T>& in) {
+  using I = HfImg<16 * T>;
+  keep_lds_reads_local();
+  matrix_phase_begin();
+  typedef fp16x4_t __attribute__((address_space(3))) * lds_h4;
+  typedef char __attribute__((address_space(3))) * lds_cp;
+  const int a4 = (ln.lane & 15) >> 2, pp = ln.lane & 3;
+  lds_cp base = (lds_cp) const_cast<char*>(reinterpret_cast<const char*>(Wimg)) + (4 * ln.q + a4) * (I::RS * 2) + 16 * pp;
+#pragma unroll
+  for (int n0 = 0; n0 < T; n0 += 2) {
+#pragma unroll
+    for (int s = 0; s < T / 2; ++s) {
+      f16x8 a[2][2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int nt = n0 + g;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          lds_cp off = base + p * I::PART + 32 * s * (I::RS * 2) + (64 * (nt >> 1) + 8 * (nt & 1));
+          f16x4 lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)off));
+          f16x4 hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(off + 16 * (I::RS * 2))));
+          a[g][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+      mfma3x2(o.v[n0], o.v[n0 + 1], a, in.h[s], in.l[s]);
+    }
+  }
+  matrix_phase_end();
+}
+
 // 16*TI units -> 4 outputs, every lane receives all 4 (row 4q+r of the MFMA tile carries output r).
 // Wt is [4][LR], LR = 16*TI + 8, row c = weights of output c.
 template <int TI>
@@ -380,16 +492,20 @@ DEV float reduce_q(float v) {  // sum over the 4 lanes (q = 0..3) of a rollout
 // ------------------------------------------------------------------------------------------------
 // LDS image layouts (offsets in floats; every section size is a multiple of 4 floats)
 // ------------------------------------------------------------------------------------------------
-template <int HID, bool BF = false>
+constexpr int MM_F32 = 0, MM_BF16X3 = 1, MM_F16X2 = 2;  // how the hidden x hidden products are evaluated
+
+template <int HID, int MM = MM_F32>
 struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int T = HID / 16, LD = HID + 4, LR = HID + 8;
-  static constexpr int oW2 = 0;                  // f32: [HID][LD];  BF: bf16x3 image (BfImg<HID>)
-  static constexpr int oW1f = oW2 + (BF ? BfImg<HID>::FLOATS : HID * LD);  // [T][64] fragment image of W1
+  static constexpr int oW2 = 0;                  // f32: [HID][LD]; bf16x3 / f16x2: BfImg / HfImg (x S for f16x2)
+  static constexpr int W2F = MM == MM_F32 ? HID * LD : (MM == MM_BF16X3 ? BfImg<HID>::FLOATS : HfImg<HID>::FLOATS);
+  static constexpr int oW1f = oW2 + W2F;         // [T][64] fragment image of W1
   static constexpr int oB1 = oW1f + T * 64;      // [HID]
-  static constexpr int oB2 = oB1 + HID;          // [HID]
-  static constexpr int oW3 = oB2 + HID;          // [HID]
-  static constexpr int oW1T = oW3 + HID;         // [4][LR] rows c = W1[:,c]
-  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 0, 0, 0)
+  static constexpr int oB2 = oB1 + HID;          // [HID]   b2 * S
+  static constexpr int oW3 = oB2 + HID;          // [HID]   w3
+  static constexpr int oW3S = oW3 + HID;         // [HID]   w3 / S (used by the Hessian-vector product)
+  static constexpr int oW1T = oW3S + HID;        // [4][LR] rows c = W1[:,c] / S
+  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 0, 0)
   static constexpr int SIZE = oB3 + 4;
 };
 
@@ -412,22 +528,34 @@ struct HTape {
   Act<HID / 16> a1, a2, q1;  // activations, and q1 = W2^T g2 (before the (1-a1^2) factor)
 };
 
-template <int HID, bool WANT_H, bool BF = false>
+template <int HID, bool WANT_H, int MM = MM_F32>
 DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hval) {
-  using Y = LayH2<HID, BF>;
+  using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(tp.a1, L + Y::oB1, ln);
   in_layer<T>(tp.a1, L + Y::oW1f, ln, sel4(z, ln.q));
   tanh_act<T>(tp.a1);
   load_vec<T>(tp.a2, L + Y::oB2, ln);
-  if (BF) {
+  if (MM == MM_BF16X3) {
     Split3<T> sp;
     split_act<T>(tp.a1, sp);
     sq_fwd_bf<T>(tp.a2, L + Y::oW2, ln, sp);
+  } else if (MM == MM_F16X2) {
+    Split2<T> sp;
+    split_act_h<T>(tp.a1, sp);
+    sq_fwd_h<T>(tp.a2, L + Y::oW2, ln, sp);
   } else {
     sq_fwd<T, T>(tp.a2, L + Y::oW2, ln, tp.a1);
   }
-  tanh_act<T>(tp.a2);
+  if (MM == MM_F16X2) {  // the accumulator holds S * z2: the scale rides in the exp2 constant
+    const float c = L[Y::oB3 + 1];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tp.a2.v[t][r] = tanh_scaled(tp.a2.v[t][r], c);
+  } else {
+    tanh_act<T>(tp.a2);
+  }
   Act<T> g;
   float s = 0.f;
   keep_lds_reads_local();
@@ -442,10 +570,14 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
   }
   if (WANT_H) Hval = reduce_q(s) + L[Y::oB3];
   zero_act<T>(tp.q1);
-  if (BF) {
+  if (MM == MM_BF16X3) {
     Split3<T> sp;
     split_act<T>(g, sp);
     sq_bwd_bf<T>(tp.q1, L + Y::oW2, ln, sp);
+  } else if (MM == MM_F16X2) {  // q1 comes out times S; W1^T in the image is divided by S
+    Split2<T> sp;
+    split_act_h<T>(g, sp);
+    sq_bwd_h<T>(tp.q1, L + Y::oW2, ln, sp);
   } else {
     sq_bwd<T, T>(tp.q1, L + Y::oW2, ln, g);
   }
@@ -456,10 +588,19 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
 
 // Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
 // (q1 is overwritten) to keep the live register set at five activation vectors.
-template <int HID, bool BF = false>
+template <int HID, int MM = MM_F32>
 DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
-  using Y = LayH2<HID, BF>;
+  using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
+  float unscale = 1.0f;
+  if (MM == MM_F16X2) {  // Hv is linear in v: bring max|v_i| into [0.5,1) by a power of two (exact), undo at the end
+    float mx = fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    int e = 0;
+    (void)__builtin_frexpf(mx, &e);
+    e = (mx > 0.f && mx < 3.0e38f) ? e : 0;
+    v = v * __builtin_ldexpf(1.0f, -e);
+    unscale = __builtin_ldexpf(1.0f, e);
+  }
   Act<T> ad1, w;
   zero_act<T>(ad1);
   in_layer<T>(ad1, L + Y::oW1f, ln, sel4(v, ln.q));
@@ -469,27 +610,35 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
 #pragma unroll
   for (int t = 0; t < T; ++t) tp.q1.v[t] = tp.q1.v[t] * (-2.0f * tp.a1.v[t] * ad1.v[t]);
   zero_act<T>(w);
-  if (BF) {
+  if (MM == MM_BF16X3) {
     Split3<T> sp;
     split_act<T>(ad1, sp);
     sq_fwd_bf<T>(w, L + Y::oW2, ln, sp);
+  } else if (MM == MM_F16X2) {
+    Split2<T> sp;
+    split_act_h<T>(ad1, sp);
+    sq_fwd_h<T>(w, L + Y::oW2, ln, sp);
   } else {
     sq_fwd<T, T>(w, L + Y::oW2, ln, ad1);
   }
   keep_lds_reads_local();
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * t + 4 * ln.q);
+    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3S + 16 * t + 4 * ln.q);  // w3 / S: w holds S * zdot2
     f32x4 a2 = tp.a2.v[t];
     f32x4 ad2 = (1.0f - a2 * a2) * w.v[t];
     w.v[t] = w3 * (-2.0f * a2 * ad2);  // gdot2
   }
   Act<T> qd;
   zero_act<T>(qd);
-  if (BF) {
+  if (MM == MM_BF16X3) {
     Split3<T> sp;
     split_act<T>(w, sp);
     sq_bwd_bf<T>(qd, L + Y::oW2, ln, sp);
+  } else if (MM == MM_F16X2) {
+    Split2<T> sp;
+    split_act_h<T>(w, sp);
+    sq_bwd_h<T>(qd, L + Y::oW2, ln, sp);
   } else {
     sq_bwd<T, T>(qd, L + Y::oW2, ln, w);
   }
@@ -498,7 +647,8 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
     f32x4 a1 = tp.a1.v[t];
     qd.v[t] = qd.v[t] * (1.0f - a1 * a1) + tp.q1.v[t];
   }
-  return to4_rep<T>(L + Y::oW1T, ln, qd);
+  f32x4 Hv = to4_rep<T>(L + Y::oW1T, ln, qd);
+  return MM == MM_F16X2 ? Hv * unscale : Hv;
 }
 
 // one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations
@@ -535,12 +685,12 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
 // ------------------------------------------------------------------------------------------------
 // Model: pHNN (src/pHNN.py:52-100)
 // ------------------------------------------------------------------------------------------------
-template <int N_, int HID_, bool FIXG_, bool BF_ = false>
+template <int N_, int HID_, bool FIXG_, int MM_ = MM_F32>
 struct PhnnModel {
-  static constexpr int N = N_, HID = HID_, T = HID / 16;
-  static constexpr bool FIXG = FIXG_, BF = BF_;
+  static constexpr int N = N_, HID = HID_, T = HID / 16, MM = MM_;
+  static constexpr bool FIXG = FIXG_;
   static constexpr int oH = 0;
-  static constexpr int oR = oH + LayH2<HID, BF>::SIZE;
+  static constexpr int oR = oH + LayH2<HID, MM>::SIZE;
   static constexpr int oGn = oR + LayH1<HID>::SIZE;
   static constexpr int oJ = oGn + (FIXG ? 0 : LayH1<HID>::SIZE);  // [16] J - J^T, row-major N x N
   static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
@@ -554,7 +704,7 @@ struct PhnnModel {
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H, BF>(L + oH, ln, x, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, x, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a1);
       store_act<T>(stash + T * 256, ln, tp.a2);
@@ -618,7 +768,7 @@ struct PhnnModel {
       load_act<T>(stash + 2 * T * 256, ln, tp.q1);
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
     } else {
-      dH = hnet_grad<HID, false, BF>(L + oH, ln, x, tp, Hdummy);
+      dH = hnet_grad<HID, false, MM>(L + oH, ln, x, tp, Hdummy);
     }
     f32x4 xb = splat4(0.f);
     float S[N][N], Stl[N], StdH[N];
@@ -683,7 +833,7 @@ struct PhnnModel {
       for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[j][k], Stl[k], acc);
       v[j] = acc;
     }
-    xbar = xb + hnet_hvp<HID, BF>(L + oH, ln, tp, v);
+    xbar = xb + hnet_hvp<HID, MM>(L + oH, ln, tp, v);
   }
 };
 
@@ -691,12 +841,11 @@ struct PhnnModel {
 // Model: canonical pHNN with the cart-pole mass matrix (src/pHNN_canonical.py:172-273,
 // src/mass_matrix.py:270-362, src/coordinate_transforms.py:20-130)
 // ------------------------------------------------------------------------------------------------
-template <int HID_, bool BF_ = false>
+template <int HID_, int MM_ = MM_F32>
 struct CanonModel {
-  static constexpr int N = 4, HID = HID_, T = HID / 16;
-  static constexpr bool BF = BF_;
+  static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_;
   static constexpr int oH = 0;
-  static constexpr int oC = oH + LayH2<HID, BF>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
+  static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
   static constexpr int IMG = oC + 12;
 
   static constexpr int STASH = 3 * T * 256 + 64;
@@ -710,7 +859,7 @@ struct CanonModel {
     float bc = b * cs;
     f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H, BF>(L + oH, ln, z, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, z, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a1);
       store_act<T>(stash + T * 256, ln, tp.a2);
@@ -743,7 +892,7 @@ struct CanonModel {
       load_act<T>(stash + 2 * T * 256, ln, tp.q1);
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
     } else {
-      dH = hnet_grad<HID, false, BF>(L + oH, ln, z, tp, Hdummy);
+      dH = hnet_grad<HID, false, MM>(L + oH, ln, z, tp, Hdummy);
     }
     float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
     float dp0 = (-dH[0] - Rd2 * dH[2]) + L[oC + 10] * u;
@@ -758,7 +907,7 @@ struct CanonModel {
     float mb11 = lam[1] * z[3] + lam[3] * dp1;
     f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
     ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
-    f32x4 zb = hnet_hvp<HID, BF>(L + oH, ln, tp, v);
+    f32x4 zb = hnet_hvp<HID, MM>(L + oH, ln, tp, v);
     zb[2] += pb0;
     zb[3] += pb1;
     float bcb = zb[2] * y[3] + zb[3] * y[2];

@@ -28,8 +28,10 @@ enum Variant {
   V_ODE_2_128,       // ODEFunc(2,1), hidden [128,128,128]
   V_ODE_2_64,
   V_ODE_3_128,
-  V_PHNN_4_128_FIX_BF,  // same models, 128x128 products as bf16x3 on the matrix pipe (default)
+  V_PHNN_4_128_FIX_BF,  // same models, 128x128 products as bf16x3 on the matrix pipe
   V_CANON_128_BF,
+  V_PHNN_4_128_FIX_H,   // same models, 128x128 products as f16x2 on the matrix pipe
+  V_CANON_128_H,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -41,8 +43,10 @@ using M_CANON_64 = CanonModel<64>;
 using M_ODE_2_128 = OdeModel<2, 128>;
 using M_ODE_2_64 = OdeModel<2, 64>;
 using M_ODE_3_128 = OdeModel<3, 128>;
-using M_PHNN_4_128_FIX_BF = PhnnModel<4, 128, true, true>;
-using M_CANON_128_BF = CanonModel<128, true>;
+using M_PHNN_4_128_FIX_BF = PhnnModel<4, 128, true, MM_BF16X3>;
+using M_CANON_128_BF = CanonModel<128, MM_BF16X3>;
+using M_PHNN_4_128_FIX_H = PhnnModel<4, 128, true, MM_F16X2>;
+using M_CANON_128_H = CanonModel<128, MM_F16X2>;
 
 struct KernelSet {
   void (*fwd[2])(RollParams);
@@ -86,6 +90,8 @@ bool kernel_set(int v, KernelSet* k) {
     case V_ODE_3_128: *k = make_set<M_ODE_3_128>("odefunc<n=3,hid=128>"); return true;
     case V_PHNN_4_128_FIX_BF: *k = make_set<M_PHNN_4_128_FIX_BF>("phnn<n=4,hid=128,fixedG,bf16x3>"); return true;
     case V_CANON_128_BF: *k = make_set<M_CANON_128_BF>("canonical<hid=128,bf16x3>"); return true;
+    case V_PHNN_4_128_FIX_H: *k = make_set<M_PHNN_4_128_FIX_H>("phnn<n=4,hid=128,fixedG,f16x2>"); return true;
+    case V_CANON_128_H: *k = make_set<M_CANON_128_H>("canonical<hid=128,f16x2>"); return true;
     default: return false;
   }
 }
@@ -131,11 +137,16 @@ bool same_hidden(const phnn_mlp_shape& s, int depth, int hid) {
   return true;
 }
 
-// PHNN_MATMUL=f32 selects the all-f32-MFMA kernels; default is the bf16x3 split on the matrix pipe where a
-// variant exists (same f32-level accuracy, see tools/probe_bf16_split.hip and DESIGN.md 3.3).
-bool use_bf16x3() {
+// How the hidden x hidden products are evaluated where a variant exists: PHNN_MATMUL = f32 | bf16x3 | f16x2
+// (tools/probe_bf16_split.hip).  Default: kDefaultMatmul.
+constexpr int kDefaultMatmul = MM_F16X2;
+int matmul_mode() {
   const char* e = getenv("PHNN_MATMUL");
-  return !(e && strcmp(e, "f32") == 0);
+  if (!e) return kDefaultMatmul;
+  if (strcmp(e, "f32") == 0) return MM_F32;
+  if (strcmp(e, "bf16x3") == 0) return MM_BF16X3;
+  if (strcmp(e, "f16x2") == 0) return MM_F16X2;
+  return kDefaultMatmul;
 }
 
 int pick_variant(const phnn_desc* d, std::string* why) {
@@ -149,7 +160,10 @@ int pick_variant(const phnn_desc* d, std::string* why) {
     int hid = d->h_net.hidden[0];
     bool ok = same_hidden(d->h_net, 2, hid) && same_hidden(d->r_net, 1, hid) &&
               (d->fixed_G || same_hidden(d->g_net, 1, hid));
-    if (ok && d->n == 4 && hid == 128 && d->fixed_G) return use_bf16x3() ? V_PHNN_4_128_FIX_BF : V_PHNN_4_128_FIX;
+    if (ok && d->n == 4 && hid == 128 && d->fixed_G) {
+      int mm = matmul_mode();
+      return mm == MM_F16X2 ? V_PHNN_4_128_FIX_H : (mm == MM_BF16X3 ? V_PHNN_4_128_FIX_BF : V_PHNN_4_128_FIX);
+    }
     if (ok && d->n == 4 && hid == 64 && d->fixed_G) return V_PHNN_4_64_FIX;
     if (ok && d->n == 2 && hid == 64 && !d->fixed_G) return V_PHNN_2_64_GNET;
     if (ok && d->n == 2 && hid == 64 && d->fixed_G) return V_PHNN_2_64_FIX;
@@ -162,7 +176,10 @@ int pick_variant(const phnn_desc* d, std::string* why) {
   }
   if (d->kind == PHNN_MODEL_CANONICAL) {
     int hid = d->h_net.hidden[0];
-    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 128) return use_bf16x3() ? V_CANON_128_BF : V_CANON_128;
+    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 128) {
+      int mm = matmul_mode();
+      return mm == MM_F16X2 ? V_CANON_128_H : (mm == MM_BF16X3 ? V_CANON_128_BF : V_CANON_128);
+    }
     if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 64) return V_CANON_64;
     snprintf(buf, sizeof buf, "canonical pHNN n=%d H_net depth %d width %d: no kernel instantiated", d->n,
              d->h_net.depth, hid);
@@ -246,23 +263,54 @@ void pack_bf16x3(float* dstf, const float* W) {
     }
 }
 
-template <int HID, bool BF>
+// W -> two f16 parts of S * W in the same permuted layout; returns S = 2^k with max|W| S in [0.5, 1)
+template <int HID>
+float pack_f16x2(float* dstf, const float* W) {
+  using I = HfImg<HID>;
+  float mx = 0.f;
+  for (int k = 0; k < HID * HID; ++k) mx = std::fmax(mx, std::fabs(W[k]));
+  int e = 0;
+  if (mx > 0.f) (void)std::frexp(mx, &e);
+  const float S = std::ldexp(1.0f, -e);
+  _Float16* dst = reinterpret_cast<_Float16*>(dstf);
+  for (int r = 0; r < HID; ++r)
+    for (int pos = 0; pos < HID; ++pos) {
+      int s = pos / 32, w = pos % 32, q = w / 8, j = w % 8;
+      int u = 32 * s + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
+      float x = W[(size_t)r * HID + u] * S;
+      _Float16 h = (_Float16)x;
+      _Float16 l = (_Float16)(x - (float)h);
+      size_t at = (size_t)r * I::RS + pos;
+      dst[at] = h;
+      dst[(size_t)I::PART / 2 + at] = l;
+    }
+  return S;
+}
+
+template <int HID, int MM>
 const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes W1,b1,W2,b2,W3,b3 from p
-  using Y = LayH2<HID, BF>;
+  using Y = LayH2<HID, MM>;
   const float* W1 = p; p += (size_t)HID * nin;
   const float* b1 = p; p += HID;
   const float* W2 = p; p += (size_t)HID * HID;
   const float* b2 = p; p += HID;
   const float* W3 = p; p += HID;
   const float* b3 = p; p += 1;
-  if (BF) pack_bf16x3<HID>(dst + Y::oW2, W2);
+  float S = 1.0f;  // power-of-two scale carried by the W2 image (f16x2 only)
+  if (MM == MM_BF16X3) pack_bf16x3<HID>(dst + Y::oW2, W2);
+  else if (MM == MM_F16X2) S = pack_f16x2<HID>(dst + Y::oW2, W2);
   else pack_rows(dst + Y::oW2, W2, HID, HID, Y::LD);
   pack_in_frag<HID>(dst + Y::oW1f, W1, nin);
   memcpy(dst + Y::oB1, b1, sizeof(float) * HID);
-  memcpy(dst + Y::oB2, b2, sizeof(float) * HID);
   memcpy(dst + Y::oW3, W3, sizeof(float) * HID);
   pack_cols_as_rows(dst + Y::oW1T, W1, HID, nin, Y::LR);
+  for (int k = 0; k < HID; ++k) {
+    dst[Y::oB2 + k] = b2[k] * S;
+    dst[Y::oW3S + k] = W3[k] / S;
+  }
+  for (int k = 0; k < 4 * Y::LR; ++k) dst[Y::oW1T + k] /= S;
   dst[Y::oB3] = b3[0];
+  dst[Y::oB3 + 1] = 2.8853900817779268f / S;
   return p;
 }
 
@@ -289,7 +337,7 @@ void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
   const float* G = nullptr;
   if (d->fixed_G) { G = p; p += N; }
   p = pack_h1<HID>(img.data() + M::oR, p, N, N * N);
-  p = pack_h2<HID, M::BF>(img.data() + M::oH, p, N);
+  p = pack_h2<HID, M::MM>(img.data() + M::oH, p, N);
   if (!d->fixed_G) p = pack_h1<HID>(img.data() + M::oGn, p, N, N);
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) img[M::oJ + i * N + j] = J[i * N + j] - J[j * N + i];  // src/pHNN.py:83, no 1/2
@@ -307,7 +355,7 @@ void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
   const float* G = p; p += 4;
   float log_a = p[0], b = p[1], log_c = p[2];
   p += 3;
-  p = pack_h2<HID, M::BF>(img.data() + M::oH, p, 4);
+  p = pack_h2<HID, M::MM>(img.data() + M::oH, p, 4);
   float* c = img.data() + M::oC;
   c[0] = expf(log_a) + 1e-3f;  // src/mass_matrix.py:286-288
   c[1] = b;
@@ -354,6 +402,8 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_ODE_3_128: pack_ode<M_ODE_3_128>(img, d, blob); break;
     case V_PHNN_4_128_FIX_BF: pack_phnn<M_PHNN_4_128_FIX_BF>(img, d, blob); break;
     case V_CANON_128_BF: pack_canon<M_CANON_128_BF>(img, d, blob); break;
+    case V_PHNN_4_128_FIX_H: pack_phnn<M_PHNN_4_128_FIX_H>(img, d, blob); break;
+    case V_CANON_128_H: pack_canon<M_CANON_128_H>(img, d, blob); break;
     default: break;
   }
 }
@@ -432,6 +482,8 @@ int check_cost(phnn_handle* h, const phnn_cost* c) {
 extern "C" {
 
 int phnn_version(void) { return 100; }
+
+const char* phnn_variant_name(const phnn_handle* h) { return h ? h->ks.name : ""; }
 
 size_t phnn_weight_count(const phnn_desc* desc) { return weight_count(desc); }
 

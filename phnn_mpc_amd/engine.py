@@ -194,6 +194,16 @@ class RolloutEngine:
                                      self._stream())
         _check(self.lib, self.h, rc)
 
+    @property
+    def variant(self):
+        """e.g. 'phnn<n=4,hid=128,fixedG,f16x2>'"""
+        return self.lib.phnn_variant_name(self.h).decode()
+
+    @property
+    def matmul_mode(self):
+        v = self.variant
+        return "f16x2" if "f16x2" in v else ("bf16x3" if "bf16x3" in v else "f32")
+
     def kernel_info(self, B, integrator="euler"):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         self.lib.phnn_kernel_info(self.h, self._integ(integrator), C.byref(a), C.byref(b), C.byref(c), int(B))

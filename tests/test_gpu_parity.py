@@ -203,9 +203,10 @@ def test_stash_and_recompute_modes_agree(bundle):
 
 
 @pytest.mark.parametrize("name", ["phnn_cartpole", "canonical_cartpole"])
-def test_f32_and_bf16x3_matmul_variants(torch_cuda, name):
-    """The 128x128 products run as a 3-way bf16 split on the matrix pipe by default; PHNN_MATMUL=f32 selects the
-    all-f32-MFMA kernels.  Both must sit within the stated tolerances of the float64 oracle."""
+def test_matmul_variants(torch_cuda, name):
+    """The 128x128 products run as an exact 2-way f16 split on the matrix pipe by default (PHNN_MATMUL=f16x2);
+    bf16x3 is the 3-way bf16 split, f32 the all-f32-MFMA kernels.  Each must sit within the stated tolerances of
+    the float64 oracle."""
     import os
     from phnn_mpc_amd.engine import RolloutEngine
     g, w = ol.load_golden(name), ol.load_weights(name)
@@ -217,7 +218,7 @@ def test_f32_and_bf16x3_matmul_variants(torch_cuda, name):
     cost = ol.cost_from_golden(g)
     ref = m64.rollout(x0, U, cost, "euler", 0.02, nthreads=8)
     res = {}
-    for mode in ("bf16x3", "f32"):
+    for mode in ("f16x2", "bf16x3", "f32"):
         os.environ["PHNN_MATMUL"] = mode
         try:
             eng = RolloutEngine(w)
@@ -228,4 +229,5 @@ def test_f32_and_bf16x3_matmul_variants(torch_cuda, name):
         assert_rollout_close(npy(c), npy(tr), npy(gu), npy(gx), ref["cost"], ref["traj"], ref["grad_u"], ref["grad_x0"])
         res[mode] = (npy(c), npy(gu))
     assert not np.array_equal(res["f32"][1], res["bf16x3"][1])  # they really are different kernels
-    assert np.allclose(res["f32"][0], res["bf16x3"][0], rtol=2e-6)
+    assert not np.array_equal(res["f16x2"][1], res["bf16x3"][1])
+    assert np.allclose(res["f32"][0], res["bf16x3"][0], rtol=2e-6) and np.allclose(res["f32"][0], res["f16x2"][0], rtol=4e-6)
