@@ -502,9 +502,10 @@ struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int oW1f = oW2 + W2F;         // [T][64] fragment image of W1
   static constexpr int oB1 = oW1f + T * 64;      // [HID]
   static constexpr int oB2 = oB1 + HID;          // [HID]   b2 * S
-  static constexpr int oW3 = oB2 + HID;          // [HID]   w3
-  static constexpr int oW3S = oW3 + HID;         // [HID]   w3 / S (used by the Hessian-vector product)
-  static constexpr int oW1T = oW3S + HID;        // [4][LR] rows c = W1[:,c] / S
+  static constexpr int oW3 = oB2 + HID;          // [HID]   w3 (Hamiltonian value)
+  static constexpr int oW3B = oW3 + HID;         // [HID]   w3 * Sb (g2 = w3 (1 - a2^2), fed to the transposed product)
+  static constexpr int oW3S = oW3B + HID;        // [HID]   w3 * Sb / S (used by the Hessian-vector product)
+  static constexpr int oW1T = oW3S + HID;        // [4][LR] rows c = W1[:,c] / (S Sb)
   static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 0, 0)
   static constexpr int SIZE = oB3 + 4;
 };
@@ -561,12 +562,13 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
   keep_lds_reads_local();
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * t + 4 * ln.q);
     if (WANT_H) {
+      f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * t + 4 * ln.q);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s = __builtin_fmaf(w3[r], tp.a2.v[t][r], s);
     }
-    g.v[t] = w3 * (1.0f - tp.a2.v[t] * tp.a2.v[t]);
+    f32x4 w3b = *reinterpret_cast<const f32x4*>(L + Y::oW3B + 16 * t + 4 * ln.q);
+    g.v[t] = w3b * (1.0f - tp.a2.v[t] * tp.a2.v[t]);
   }
   if (WANT_H) Hval = reduce_q(s) + L[Y::oB3];
   zero_act<T>(tp.q1);
@@ -584,6 +586,16 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
 #pragma unroll
   for (int t = 0; t < T; ++t) g.v[t] = tp.q1.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
   return to4_rep<T>(L + Y::oW1T, ln, g);
+}
+
+// first hidden activation of H_net from its input: cheap (one k-step, 8 f32 MFMAs + tanh) -- K2 recomputes it
+// instead of reading it from the stash, which cuts the stash traffic by a third
+template <int HID, int MM>
+DEV void hnet_layer1(const float* L, Lane ln, f32x4 z, Act<HID / 16>& a1) {
+  using Y = LayH2<HID, MM>;
+  load_vec<Y::T>(a1, L + Y::oB1, ln);
+  in_layer<Y::T>(a1, L + Y::oW1f, ln, sel4(z, ln.q));
+  tanh_act<Y::T>(a1);
 }
 
 // Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
@@ -696,8 +708,8 @@ struct PhnnModel {
   static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
   static constexpr int IMG = oG + 4;
 
-  // floats one wave stashes per step for the adjoint: a1, a2, q1 (T x 256 each) + dH (16 x 4)
-  static constexpr int STASH = 3 * T * 256 + 64;
+  // floats one wave stashes per step for the adjoint: a2, q1 (T x 256 each) + dH (16 x 4); a1 is recomputed
+  static constexpr int STASH = 2 * T * 256 + 64;
 
   // dx = (Jeff - S S^T) dH + G u, with S = sym(R_raw).  stash != null: keep the H_net tape for K2.
   template <bool WANT_H, bool ST = false>
@@ -706,10 +718,9 @@ struct PhnnModel {
     HTape<HID> tp;
     f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, x, tp, Hval);
     if (ST) {
-      store_act<T>(stash, ln, tp.a1);
-      store_act<T>(stash + T * 256, ln, tp.a2);
-      store_act<T>(stash + 2 * T * 256, ln, tp.q1);
-      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 3 * T * 256) + ln.i);
+      store_act<T>(stash, ln, tp.a2);
+      store_act<T>(stash + T * 256, ln, tp.q1);
+      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
     }
     Act<T> hR;
     float rf[16];
@@ -762,11 +773,11 @@ struct PhnnModel {
     HTape<HID> tp;
     float Hdummy;
     f32x4 dH;
-    if (ST) {  // tape written by K1: the loads fly while the R_net part below runs
-      load_act<T>(stash, ln, tp.a1);
-      load_act<T>(stash + T * 256, ln, tp.a2);
-      load_act<T>(stash + 2 * T * 256, ln, tp.q1);
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
+    if (ST) {  // tape written by K1: the loads fly while a1 is recomputed and the R_net part below runs
+      load_act<T>(stash, ln, tp.a2);
+      load_act<T>(stash + T * 256, ln, tp.q1);
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      hnet_layer1<HID, MM>(L + oH, ln, x, tp.a1);
     } else {
       dH = hnet_grad<HID, false, MM>(L + oH, ln, x, tp, Hdummy);
     }
@@ -848,7 +859,7 @@ struct CanonModel {
   static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
   static constexpr int IMG = oC + 12;
 
-  static constexpr int STASH = 3 * T * 256 + 64;
+  static constexpr int STASH = 2 * T * 256 + 64;
 
   template <bool WANT_H, bool ST = false>
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, float u, float& Hval, float* stash = nullptr) {
@@ -861,10 +872,9 @@ struct CanonModel {
     HTape<HID> tp;
     f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, z, tp, Hval);
     if (ST) {
-      store_act<T>(stash, ln, tp.a1);
-      store_act<T>(stash + T * 256, ln, tp.a2);
-      store_act<T>(stash + 2 * T * 256, ln, tp.q1);
-      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 3 * T * 256) + ln.i);
+      store_act<T>(stash, ln, tp.a2);
+      store_act<T>(stash + T * 256, ln, tp.q1);
+      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
     }
     float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + L[oC + 10] * u;
     float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + L[oC + 11] * u;
@@ -887,10 +897,10 @@ struct CanonModel {
     float Hdummy;
     f32x4 dH;
     if (ST) {
-      load_act<T>(stash, ln, tp.a1);
-      load_act<T>(stash + T * 256, ln, tp.a2);
-      load_act<T>(stash + 2 * T * 256, ln, tp.q1);
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 3 * T * 256) + ln.i);
+      load_act<T>(stash, ln, tp.a2);
+      load_act<T>(stash + T * 256, ln, tp.q1);
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
     } else {
       dH = hnet_grad<HID, false, MM>(L + oH, ln, z, tp, Hdummy);
     }

@@ -304,11 +304,29 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   memcpy(dst + Y::oB1, b1, sizeof(float) * HID);
   memcpy(dst + Y::oW3, W3, sizeof(float) * HID);
   pack_cols_as_rows(dst + Y::oW1T, W1, HID, nin, Y::LR);
+  // Sb: power of two (<= 1) that keeps the backward-type MFMA inputs g2 = w3 (1-a2^2) and
+  // gdot2 = w3 (-2 a2 (1-a2^2)) zdot2 inside f16 range for any weights: |g2| <= max|w3| and, with the
+  // Hessian-vector input normalised below 1, |gdot2| <= 0.77 max|w3| ||W2||_inf ||W1||_inf.  1 for ordinary weights.
+  float Sb = 1.0f;
+  if (MM == MM_F16X2) {
+    float w3max = 0.f, n1 = 0.f, n2 = 0.f;
+    for (int k = 0; k < HID; ++k) w3max = std::fmax(w3max, std::fabs(W3[k]));
+    for (int r = 0; r < HID; ++r) {
+      float a = 0.f, b = 0.f;
+      for (int c = 0; c < nin; ++c) a += std::fabs(W1[(size_t)r * nin + c]);
+      for (int c = 0; c < HID; ++c) b += std::fabs(W2[(size_t)r * HID + c]);
+      n1 = std::fmax(n1, a);
+      n2 = std::fmax(n2, b);
+    }
+    float bound = std::fmax(w3max, 0.77f * w3max * n1 * n2);
+    while (bound * Sb > 1024.0f) Sb *= 0.5f;
+  }
   for (int k = 0; k < HID; ++k) {
     dst[Y::oB2 + k] = b2[k] * S;
-    dst[Y::oW3S + k] = W3[k] / S;
+    dst[Y::oW3B + k] = W3[k] * Sb;
+    dst[Y::oW3S + k] = W3[k] * Sb / S;
   }
-  for (int k = 0; k < 4 * Y::LR; ++k) dst[Y::oW1T + k] /= S;
+  for (int k = 0; k < 4 * Y::LR; ++k) dst[Y::oW1T + k] /= (S * Sb);
   dst[Y::oB3] = b3[0];
   dst[Y::oB3 + 1] = 2.8853900817779268f / S;
   return p;

@@ -231,3 +231,29 @@ def test_matmul_variants(torch_cuda, name):
     assert not np.array_equal(res["f32"][1], res["bf16x3"][1])  # they really are different kernels
     assert not np.array_equal(res["f16x2"][1], res["bf16x3"][1])
     assert np.allclose(res["f32"][0], res["bf16x3"][0], rtol=2e-6) and np.allclose(res["f32"][0], res["f16x2"][0], rtol=4e-6)
+
+
+def test_f16x2_scaling_with_extreme_weights(torch_cuda):
+    """Weights far outside f16's comfortable range (output layer x 2e4, hidden layer x 6, tiny first layer): the
+    power-of-two scales of the f16x2 path (S on W2, Sb on the backward-type operands, per-rollout normalisation of
+    the Hessian-vector input) must keep model(x,u) and its VJP at f32 accuracy."""
+    from phnn_mpc_amd.engine import RolloutEngine
+    g = ol.load_golden("phnn_cartpole")
+    w = dict(ol.load_weights("phnn_cartpole"))
+    w["H_net.net.4.weight"] = w["H_net.net.4.weight"] * np.float32(2.0e4)
+    w["H_net.net.2.weight"] = w["H_net.net.2.weight"] * np.float32(6.0)
+    w["H_net.net.0.weight"] = w["H_net.net.0.weight"] * np.float32(0.05)
+    eng, m64 = RolloutEngine(w), ol.OracleModel(w, "f64")
+    assert eng.matmul_mode == "f16x2"
+    x, u = g["vjp_x"], g["vjp_u"]
+    lam = g["vjp_lam"] * np.float32(1.0e-6)  # tiny and, below, huge cotangents
+    for scale in (1.0, 1.0e9):
+        l2 = (lam * np.float32(scale)).astype(np.float32)
+        xb, ub = eng.vjp(x, u, l2)
+        rxb, rub = m64.vjp(x, u, l2)
+        assert np.abs(npy(xb) - rxb).max() <= 3e-5 * np.abs(rxb).max()
+        assert np.abs(npy(ub) - rub).max() <= 3e-5 * max(np.abs(rub).max(), 1e-30)
+    dx, H = eng.forward(g["fwd_x"], g["fwd_u"])
+    rdx, rH = m64.forward(g["fwd_x"], g["fwd_u"])
+    assert np.abs(npy(dx) - rdx).max() <= 3e-5 * np.abs(rdx).max()
+    assert np.abs(npy(H) - rH).max() <= 3e-5 * np.abs(rH).max()
