@@ -144,6 +144,20 @@ DEV void sq_fwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
   constexpr int LD = 16 * TI + 4;
   keep_lds_reads_local();
   const float* base = W + ln.i * LD + 4 * ln.q;
+  if (TO == 1) {
+    // a single output tile would be one chain of 4*TI dependent MFMAs (40-cycle latency each): use two partial sums
+    f32x4 e = o.v[0], d = splat4(0.f);
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(base + 16 * t);
+      e = mfma(a[0], in.v[t][0], e);
+      d = mfma(a[1], in.v[t][1], d);
+      e = mfma(a[2], in.v[t][2], e);
+      d = mfma(a[3], in.v[t][3], d);
+    }
+    o.v[0] = e + d;
+    return;
+  }
   constexpr int G = TO < 4 ? TO : 4;
 #pragma unroll
   for (int t = 0; t < TI; ++t) {
