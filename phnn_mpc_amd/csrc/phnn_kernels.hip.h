@@ -715,6 +715,7 @@ template <int N_, int HID_, bool FIXG_, int MM_ = MM_F32>
 struct PhnnModel {
   static constexpr int N = N_, HID = HID_, T = HID / 16, MM = MM_;
   static constexpr bool FIXG = FIXG_;
+  static constexpr int SCR = kScrFloats;  // per-wave LDS scratch (exchange of the 16 R_net / G_net outputs)
   static constexpr int oH = 0;
   static constexpr int oR = oH + LayH2<HID, MM>::SIZE;
   static constexpr int oGn = oR + LayH1<HID>::SIZE;
@@ -869,6 +870,7 @@ struct PhnnModel {
 template <int HID_, int MM_ = MM_F32>
 struct CanonModel {
   static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_;
+  static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int oH = 0;
   static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
   static constexpr int IMG = oC + 12;
@@ -945,43 +947,77 @@ struct CanonModel {
 // ------------------------------------------------------------------------------------------------
 // Model: ODEFunc MLP [x,u] -> HID -> HID -> HID -> n  (src/baseline_node.py:60-116), n + m <= 4
 // ------------------------------------------------------------------------------------------------
-template <int N_, int HID_>
+template <int N_, int HID_, int MM_ = MM_F32>
 struct OdeModel {
-  static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8;
+  static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8, MM = MM_;
+  static constexpr int SCR = 0;  // no per-wave LDS scratch needed
+  static constexpr int WF = MM == MM_F16X2 ? HfImg<HID>::FLOATS : HID * LD;  // one hidden x hidden image
   static constexpr int oW1f = 0;                   // [T][64]   W1 (HID x (n+m))
   static constexpr int oB1 = oW1f + T * 64;        // [HID]
-  static constexpr int oW2 = oB1 + HID;            // [HID][LD]
-  static constexpr int oB2 = oW2 + HID * LD;
-  static constexpr int oW3 = oB2 + HID;            // [HID][LD]
-  static constexpr int oB3 = oW3 + HID * LD;
+  static constexpr int oW2 = oB1 + HID;            // f32: [HID][LD]; f16x2: HfImg of S2 * W2
+  static constexpr int oB2 = oW2 + WF;             // [HID]  b2 * S2
+  static constexpr int oW3 = oB2 + HID;            // like oW2, scale S3
+  static constexpr int oB3 = oW3 + WF;             // [HID]  b3 * S3
   static constexpr int oW4r = oB3 + HID;           // [4][LR] rows c = W4[c,:]
   static constexpr int oB4 = oW4r + 4 * LR;        // [4]
   static constexpr int oW4f = oB4 + 4;             // [T][64] fragment image of W4^T (HID x n)
-  static constexpr int oW1T = oW4f + T * 64;       // [4][LR] rows c = W1[:,c]
-  static constexpr int IMG = oW1T + 4 * LR;
+  static constexpr int oW1T = oW4f + T * 64;       // [4][LR] rows c = W1[:,c] / (S2 S3)
+  static constexpr int oSC = oW1T + 4 * LR;        // [4] (2 log2 e / S2, 2 log2 e / S3, 0, 0)
+  static constexpr int IMG = oSC + 4;
+  static_assert(MM != MM_BF16X3, "ODEFunc has an f32 and an f16x2 variant");
 
   struct Tape {
     Act<T> a1, a2, a3;
   };
 
-  DEV static f32x4 fwd(const float* L, Lane ln, f32x4 x, float u, Tape& tp) {
-    keep_lds_reads_local();
+  DEV static void layer1(const float* L, Lane ln, f32x4 x, float u, Act<T>& a1) {
     f32x4 in = x;
     in[N] = u;  // N + 1 <= 4
-    load_vec<T>(tp.a1, L + oB1, ln);
-    in_layer<T>(tp.a1, L + oW1f, ln, sel4(in, ln.q));
-    tanh_act<T>(tp.a1);
-    load_vec<T>(tp.a2, L + oB2, ln);
-    sq_fwd<T, T>(tp.a2, L + oW2, ln, tp.a1);
-    tanh_act<T>(tp.a2);
-    load_vec<T>(tp.a3, L + oB3, ln);
-    sq_fwd<T, T>(tp.a3, L + oW3, ln, tp.a2);
-    tanh_act<T>(tp.a3);
+    load_vec<T>(a1, L + oB1, ln);
+    in_layer<T>(a1, L + oW1f, ln, sel4(in, ln.q));
+    tanh_act<T>(a1);
+  }
+
+  // hidden -> hidden layer: o = tanh(b + W a)
+  DEV static void hidden(const float* L, Lane ln, int oW, int oB, float c, const Act<T>& a, Act<T>& o) {
+    load_vec<T>(o, L + oB, ln);
+    if (MM == MM_F16X2) {
+      Split2<T> sp;
+      split_act_h<T>(a, sp);
+      sq_fwd_h<T>(o, L + oW, ln, sp);
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.v[t][r] = tanh_scaled(o.v[t][r], c);
+    } else {
+      sq_fwd<T, T>(o, L + oW, ln, a);
+      tanh_act<T>(o);
+    }
+  }
+
+  // o = W^T d (times the image's scale in f16x2 mode)
+  DEV static void hidden_T(const float* L, Lane ln, int oW, const Act<T>& d, Act<T>& o) {
+    zero_act<T>(o);
+    if (MM == MM_F16X2) {
+      Split2<T> sp;
+      split_act_h<T>(d, sp);
+      sq_bwd_h<T>(o, L + oW, ln, sp);
+    } else {
+      sq_bwd<T, T>(o, L + oW, ln, d);
+    }
+  }
+
+  DEV static f32x4 fwd(const float* L, Lane ln, f32x4 x, float u, Tape& tp) {
+    keep_lds_reads_local();
+    layer1(L, ln, x, u, tp.a1);
+    hidden(L, ln, oW2, oB2, L[oSC + 0], tp.a1, tp.a2);
+    hidden(L, ln, oW3, oB3, L[oSC + 1], tp.a2, tp.a3);
     f32x4 b4 = *reinterpret_cast<const f32x4*>(L + oB4);
     return to4_rep<T>(L + oW4r, ln, tp.a3) + b4;
   }
 
-  static constexpr int STASH = 3 * T * 256;
+  // floats one wave stashes per step: a2, a3 (a1 is recomputed from (x,u))
+  static constexpr int STASH = 2 * T * 256;
 
   template <bool WANT_H, bool ST = false>
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
@@ -989,9 +1025,8 @@ struct OdeModel {
     if (WANT_H) Hval = 0.f;
     f32x4 dx = fwd(L, ln, x, u, tp);
     if (ST) {
-      store_act<T>(stash, ln, tp.a1);
-      store_act<T>(stash + T * 256, ln, tp.a2);
-      store_act<T>(stash + 2 * T * 256, ln, tp.a3);
+      store_act<T>(stash, ln, tp.a2);
+      store_act<T>(stash + T * 256, ln, tp.a3);
     }
     return dx;
   }
@@ -1001,26 +1036,35 @@ struct OdeModel {
                       const float* stash = nullptr) {
     Tape tp;
     if (ST) {
-      load_act<T>(stash, ln, tp.a1);
-      load_act<T>(stash + T * 256, ln, tp.a2);
-      load_act<T>(stash + 2 * T * 256, ln, tp.a3);
+      load_act<T>(stash, ln, tp.a2);
+      load_act<T>(stash + T * 256, ln, tp.a3);
+      keep_lds_reads_local();
+      layer1(L, ln, x, u, tp.a1);
     } else {
       (void)fwd(L, ln, x, u, tp);
+    }
+    float unscale = 1.0f;
+    if (MM == MM_F16X2) {  // the backward chain is linear in lam: normalise by a power of two (exact)
+      float mx = fmaxf(fmaxf(__builtin_fabsf(lam[0]), __builtin_fabsf(lam[1])), fmaxf(__builtin_fabsf(lam[2]), __builtin_fabsf(lam[3])));
+      int e = 0;
+      (void)__builtin_frexpf(mx, &e);
+      e = (mx > 0.f && mx < 3.0e38f) ? e : 0;
+      lam = lam * __builtin_ldexpf(1.0f, -e);
+      unscale = __builtin_ldexpf(1.0f, e);
     }
     Act<T> d, e;
     zero_act<T>(d);
     in_layer<T>(d, L + oW4f, ln, sel4(lam, ln.q));
 #pragma unroll
     for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * (1.0f - tp.a3.v[t] * tp.a3.v[t]);
-    zero_act<T>(e);
-    sq_bwd<T, T>(e, L + oW3, ln, d);
+    hidden_T(L, ln, oW3, d, e);
 #pragma unroll
     for (int t = 0; t < T; ++t) e.v[t] = e.v[t] * (1.0f - tp.a2.v[t] * tp.a2.v[t]);
-    zero_act<T>(d);
-    sq_bwd<T, T>(d, L + oW2, ln, e);
+    hidden_T(L, ln, oW2, e, d);
 #pragma unroll
     for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
     f32x4 inb = to4_rep<T>(L + oW1T, ln, d);
+    if (MM == MM_F16X2) inb = inb * unscale;
     ubar = inb[N];
     inb[N] = 0.f;
     xbar = inb;
@@ -1151,7 +1195,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
-  float* scr = lds + M::IMG + wave * kScrFloats;
+  float* scr = lds + M::IMG + wave * M::SCR;
   const long long tile = (long long)blockIdx.x * nwaves + wave;
   if (tile * kTileB >= p.B) return;
   long long b = tile * kTileB + ln.i;
@@ -1194,7 +1238,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
-  float* scr = lds + M::IMG + wave * kScrFloats;
+  float* scr = lds + M::IMG + wave * M::SCR;
   const long long tile = (long long)blockIdx.x * nwaves + wave;
   if (tile * kTileB >= p.B) return;
   long long b = tile * kTileB + ln.i;
@@ -1258,7 +1302,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_forward(PointParams p)
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
-  float* scr = lds + M::IMG + wave * kScrFloats;
+  float* scr = lds + M::IMG + wave * M::SCR;
   const long long ntiles = (p.B + kTileB - 1) / kTileB;
   for (long long tile = (long long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long long)gridDim.x * nwaves) {
     long long b = tile * kTileB + ln.i;
@@ -1284,7 +1328,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_vjp(PointParams p) {
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
-  float* scr = lds + M::IMG + wave * kScrFloats;
+  float* scr = lds + M::IMG + wave * M::SCR;
   const long long ntiles = (p.B + kTileB - 1) / kTileB;
   for (long long tile = (long long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long long)gridDim.x * nwaves) {
     long long b = tile * kTileB + ln.i;

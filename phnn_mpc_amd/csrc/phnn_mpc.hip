@@ -32,6 +32,8 @@ enum Variant {
   V_CANON_128_BF,
   V_PHNN_4_128_FIX_H,   // same models, 128x128 products as f16x2 on the matrix pipe
   V_CANON_128_H,
+  V_ODE_2_128_H,
+  V_ODE_3_128_H,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -47,6 +49,8 @@ using M_PHNN_4_128_FIX_BF = PhnnModel<4, 128, true, MM_BF16X3>;
 using M_CANON_128_BF = CanonModel<128, MM_BF16X3>;
 using M_PHNN_4_128_FIX_H = PhnnModel<4, 128, true, MM_F16X2>;
 using M_CANON_128_H = CanonModel<128, MM_F16X2>;
+using M_ODE_2_128_H = OdeModel<2, 128, MM_F16X2>;
+using M_ODE_3_128_H = OdeModel<3, 128, MM_F16X2>;
 
 struct KernelSet {
   void (*fwd[2])(RollParams);
@@ -54,6 +58,7 @@ struct KernelSet {
   void (*fwd_stash)(RollParams);   // Euler, K1 keeps the tape for K2
   void (*grad_stash)(RollParams);  // Euler, K2 reads the tape instead of recomputing it
   int stash_floats;                // per wave (16 rollouts) per step
+  int scr_floats;                  // per-wave LDS scratch
   void (*mfwd)(PointParams);
   void (*mvjp)(PointParams);
   int img_floats;
@@ -70,6 +75,7 @@ KernelSet make_set(const char* name) {
   k.fwd_stash = k_rollout_fwd<M, PHNN_INTEG_EULER, true>;
   k.grad_stash = k_rollout_grad<M, PHNN_INTEG_EULER, true>;
   k.stash_floats = M::STASH;
+  k.scr_floats = M::SCR;
   k.mfwd = k_model_forward<M>;
   k.mvjp = k_model_vjp<M>;
   k.img_floats = M::IMG;
@@ -92,6 +98,8 @@ bool kernel_set(int v, KernelSet* k) {
     case V_CANON_128_BF: *k = make_set<M_CANON_128_BF>("canonical<hid=128,bf16x3>"); return true;
     case V_PHNN_4_128_FIX_H: *k = make_set<M_PHNN_4_128_FIX_H>("phnn<n=4,hid=128,fixedG,f16x2>"); return true;
     case V_CANON_128_H: *k = make_set<M_CANON_128_H>("canonical<hid=128,f16x2>"); return true;
+    case V_ODE_2_128_H: *k = make_set<M_ODE_2_128_H>("odefunc<n=2,hid=128,f16x2>"); return true;
+    case V_ODE_3_128_H: *k = make_set<M_ODE_3_128_H>("odefunc<n=3,hid=128,f16x2>"); return true;
     default: return false;
   }
 }
@@ -189,9 +197,9 @@ int pick_variant(const phnn_desc* d, std::string* why) {
   if (d->kind == PHNN_MODEL_ODEFUNC) {
     int hid = d->h_net.hidden[0];
     bool ok = same_hidden(d->h_net, 3, hid);
-    if (ok && d->n == 2 && hid == 128) return V_ODE_2_128;
+    if (ok && d->n == 2 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_2_128_H : V_ODE_2_128;
     if (ok && d->n == 2 && hid == 64) return V_ODE_2_64;
-    if (ok && d->n == 3 && hid == 128) return V_ODE_3_128;
+    if (ok && d->n == 3 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_3_128_H : V_ODE_3_128;
     snprintf(buf, sizeof buf, "ODEFunc n=%d depth %d width %d: no kernel instantiated (need n+m<=4, 3 hidden)",
              d->n, d->h_net.depth, hid);
     *why = buf;
@@ -395,16 +403,27 @@ void pack_ode(std::vector<float>& img, const phnn_desc* d, const float* p) {
   const float* b3 = p; p += HID;
   const float* W4 = p; p += (size_t)N * HID;
   const float* b4 = p; p += N;
+  float S2 = 1.0f, S3 = 1.0f;  // power-of-two scales carried by the f16x2 images
   pack_in_frag<HID>(img.data() + M::oW1f, W1, nin);
   memcpy(img.data() + M::oB1, b1, sizeof(float) * HID);
-  pack_rows(img.data() + M::oW2, W2, HID, HID, M::LD);
-  memcpy(img.data() + M::oB2, b2, sizeof(float) * HID);
-  pack_rows(img.data() + M::oW3, W3, HID, HID, M::LD);
-  memcpy(img.data() + M::oB3, b3, sizeof(float) * HID);
+  if (M::MM == MM_F16X2) {
+    S2 = pack_f16x2<HID>(img.data() + M::oW2, W2);
+    S3 = pack_f16x2<HID>(img.data() + M::oW3, W3);
+  } else {
+    pack_rows(img.data() + M::oW2, W2, HID, HID, M::LD);
+    pack_rows(img.data() + M::oW3, W3, HID, HID, M::LD);
+  }
+  for (int k = 0; k < HID; ++k) {
+    img[M::oB2 + k] = b2[k] * S2;
+    img[M::oB3 + k] = b3[k] * S3;
+  }
   pack_rows(img.data() + M::oW4r, W4, N, HID, M::LR);
   memcpy(img.data() + M::oB4, b4, sizeof(float) * N);
   pack_in_frag_T<HID>(img.data() + M::oW4f, W4, N);
   pack_cols_as_rows(img.data() + M::oW1T, W1, HID, nin, M::LR);
+  for (int k = 0; k < 4 * M::LR; ++k) img[M::oW1T + k] /= (S2 * S3);
+  img[M::oSC + 0] = 2.8853900817779268f / S2;
+  img[M::oSC + 1] = 2.8853900817779268f / S3;
 }
 
 void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float* blob) {
@@ -422,6 +441,8 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_CANON_128_BF: pack_canon<M_CANON_128_BF>(img, d, blob); break;
     case V_PHNN_4_128_FIX_H: pack_phnn<M_PHNN_4_128_FIX_H>(img, d, blob); break;
     case V_CANON_128_H: pack_canon<M_CANON_128_H>(img, d, blob); break;
+    case V_ODE_2_128_H: pack_ode<M_ODE_2_128_H>(img, d, blob); break;
+    case V_ODE_3_128_H: pack_ode<M_ODE_3_128_H>(img, d, blob); break;
     default: break;
   }
 }
@@ -468,7 +489,8 @@ int launch(phnn_handle* h, void (*kern)(P), const P& p, long long tiles, bool gr
   long long grid = (tiles + waves - 1) / waves;
   if (grid_stride && grid > 4LL * h->n_cu) grid = 4LL * h->n_cu;
   if (grid < 1) grid = 1;
-  size_t shmem = sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * kScrFloats);
+  size_t shmem = sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * h->ks.scr_floats);
+  if (shmem > 160 * 1024) return fail(h, PHNN_ERR_UNSUPPORTED, "weight image does not fit the 160 KiB of LDS");
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)shmem);
   if (e != hipSuccess) return hip_fail(h, e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -707,7 +729,7 @@ int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts
   long long tiles = (B + kTileB - 1) / kTileB;
   int waves = pick_waves(tiles, h->n_cu);
   if (rollouts_per_wg) *rollouts_per_wg = waves * kTileB;
-  if (lds_bytes) *lds_bytes = (int32_t)(sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * kScrFloats));
+  if (lds_bytes) *lds_bytes = (int32_t)(sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * h->ks.scr_floats));
   if (n_workgroups_for_B) *n_workgroups_for_B = (int32_t)((tiles + waves - 1) / waves);
   return PHNN_OK;
 }
