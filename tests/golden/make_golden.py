@@ -21,6 +21,7 @@ Vector sets:
   G9 soft state barrier (MPCController x_min/x_max) golden_controllers.npz  bar_*
   G10 reverse pass with trajectory + cost cotangents golden_<model>.npz  tvjp_*
   G11 the NumPy plant CartPoleSimulator.step         golden_controllers.npz  plant_*
+  G12 coordinate transforms with the cart-pole M_net golden_controllers.npz  ct_*
 Each quantity is stored twice: *_f64 from the reference cast to double, *_f32 from the
 reference as shipped (float32, torch CPU).
 """
@@ -307,6 +308,16 @@ def main():
         dones.append(np.array(db))
     ctl["plant_init"], ctl["plant_forces"] = init, forces
     ctl["plant_states"], ctl["plant_done"] = np.stack(traj, axis=1), np.stack(dones, axis=1)
+    # G12: coordinate transforms with the canonical model's mass matrix (src/coordinate_transforms.py:20-130)
+    import coordinate_transforms as CT
+    rngc = np.random.default_rng(13)
+    yk = (rngc.uniform(-1, 1, size=(32, 4)) * np.array([1.0, 3.0, 2.0, 2.0])).astype(np.float32)
+    yt = torch.tensor(yk)
+    zc = CT.kinematic_to_canonical(yt, can.M_net)
+    ctl["ct_y"], ctl["ct_z"] = yk, zc.detach().numpy()
+    ctl["ct_y_back"] = CT.canonical_to_kinematic(zc, can.M_net).detach().numpy()
+    ctl["ct_p"] = CT.velocity_to_momentum(yt[:, :2], yt[:, 2:], can.M_net).detach().numpy()
+    ctl["ct_vrec"] = can.get_velocity_reconstruction(yt).detach().numpy()
     np.savez(os.path.join(OUT, "golden_controllers.npz"), **ctl)
 
     # ------------------------------------------------------------------ G8 dataset windows

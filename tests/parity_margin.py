@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Print how far the GPU results sit from the stated tolerances (fraction of tolerance used), per model/integrator.
-Run on the GPU box: python tools/parity_margin.py"""
+Run on the GPU box: python tests/parity_margin.py  (test infrastructure: uses the CPU oracle)"""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # oracle: test infrastructure
 import oracle_lib as ol  # noqa: E402
 from phnn_mpc_amd.engine import RolloutEngine  # noqa: E402
 

@@ -280,3 +280,18 @@ def test_batched_closed_loop_equals_per_plant_loops():
                 assert np.array_equal(x, out["states"][t + 1, b])
     rep = stability_report(out["states"], [0, 0, 0, 0], cfg["stability"]["tolerance"], cfg["stability"]["min_duration"], 0.02)
     assert rep["stable"].shape == (3,) and rep["longest_run_s"].shape == (3,)
+
+
+def test_coordinate_transforms_match_reference_g12(ctl):
+    from phnn_mpc_amd import coordinate_transforms as CT
+    m = pHNN_Canonical(CFG)
+    m.load_state_dict({k: torch.tensor(v) for k, v in ol.load_weights("canonical_cartpole").items()})
+    y = torch.tensor(ctl["ct_y"])
+    z = CT.kinematic_to_canonical(y, m.M_net)
+    assert np.allclose(z.numpy(), ctl["ct_z"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(CT.canonical_to_kinematic(z, m.M_net).numpy(), ctl["ct_y_back"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(CT.velocity_to_momentum(y[:, :2], y[:, 2:], m.M_net).numpy(), ctl["ct_p"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(m.get_velocity_reconstruction(y).numpy(), ctl["ct_vrec"], rtol=1e-6, atol=1e-6)
+    q, v = CT.split_state(y)
+    assert q.shape == (32, 2) and v.shape == (32, 2)
+    assert m.M_net.get_parameters_dict().keys() == {"a", "b", "c"}
