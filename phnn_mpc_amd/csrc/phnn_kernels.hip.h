@@ -963,8 +963,14 @@ struct OdeModel {
   static constexpr int oW4f = oB4 + 4;             // [T][64] fragment image of W4^T (HID x n)
   static constexpr int oW1T = oW4f + T * 64;       // [4][LR] rows c = W1[:,c] / (S2 S3)
   static constexpr int oSC = oW1T + 4 * LR;        // [4] (2 log2 e / S2, 2 log2 e / S3, 0, 0)
-  static constexpr int IMG = oSC + 4;
+  // n + m = 5 (the reference's default cart-pole ODEFunc(4,1)): the control column of W1 gets its own fragment
+  // image (second k-step of the first layer) and its own replicated-row image (ubar)
+  static constexpr bool WIDE = N + 1 > 4;
+  static constexpr int oW1fu = oSC + 4;                    // [T][64]  lane (i, q=0) holds W1[16nt+i][N]
+  static constexpr int oW1Tu = oW1fu + (WIDE ? T * 64 : 0);  // [4][LR] row 0 = W1[:,N] / (S2 S3)
+  static constexpr int IMG = oW1Tu + (WIDE ? 4 * LR : 0);
   static_assert(MM != MM_BF16X3, "ODEFunc has an f32 and an f16x2 variant");
+  static_assert(N <= 4, "state dimension up to 4");
 
   struct Tape {
     Act<T> a1, a2, a3;
@@ -972,9 +978,10 @@ struct OdeModel {
 
   DEV static void layer1(const float* L, Lane ln, f32x4 x, float u, Act<T>& a1) {
     f32x4 in = x;
-    in[N] = u;  // N + 1 <= 4
+    if (!WIDE) in[N & 3] = u;
     load_vec<T>(a1, L + oB1, ln);
     in_layer<T>(a1, L + oW1f, ln, sel4(in, ln.q));
+    if (WIDE) in_layer<T>(a1, L + oW1fu, ln, ln.q == 0 ? u : 0.f);
     tanh_act<T>(a1);
   }
 
@@ -1065,8 +1072,12 @@ struct OdeModel {
     for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
     f32x4 inb = to4_rep<T>(L + oW1T, ln, d);
     if (MM == MM_F16X2) inb = inb * unscale;
-    ubar = inb[N];
-    inb[N] = 0.f;
+    if (WIDE) {
+      ubar = to4_rep<T>(L + oW1Tu, ln, d)[0] * unscale;
+    } else {
+      ubar = inb[N & 3];
+      inb[N & 3] = 0.f;
+    }
     xbar = inb;
   }
 };

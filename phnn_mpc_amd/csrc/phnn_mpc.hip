@@ -34,6 +34,7 @@ enum Variant {
   V_CANON_128_H,
   V_ODE_2_128_H,
   V_ODE_3_128_H,
+  V_ODE_4_128,  // the reference's default ODEFunc(4,1): 5 inputs; f32 only (the f16x2 image would not fit LDS)
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -51,6 +52,7 @@ using M_PHNN_4_128_FIX_H = PhnnModel<4, 128, true, MM_F16X2>;
 using M_CANON_128_H = CanonModel<128, MM_F16X2>;
 using M_ODE_2_128_H = OdeModel<2, 128, MM_F16X2>;
 using M_ODE_3_128_H = OdeModel<3, 128, MM_F16X2>;
+using M_ODE_4_128 = OdeModel<4, 128>;
 
 struct KernelSet {
   void (*fwd[2])(RollParams);
@@ -100,6 +102,7 @@ bool kernel_set(int v, KernelSet* k) {
     case V_CANON_128_H: *k = make_set<M_CANON_128_H>("canonical<hid=128,f16x2>"); return true;
     case V_ODE_2_128_H: *k = make_set<M_ODE_2_128_H>("odefunc<n=2,hid=128,f16x2>"); return true;
     case V_ODE_3_128_H: *k = make_set<M_ODE_3_128_H>("odefunc<n=3,hid=128,f16x2>"); return true;
+    case V_ODE_4_128: *k = make_set<M_ODE_4_128>("odefunc<n=4,hid=128>"); return true;
     default: return false;
   }
 }
@@ -200,7 +203,8 @@ int pick_variant(const phnn_desc* d, std::string* why) {
     if (ok && d->n == 2 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_2_128_H : V_ODE_2_128;
     if (ok && d->n == 2 && hid == 64) return V_ODE_2_64;
     if (ok && d->n == 3 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_3_128_H : V_ODE_3_128;
-    snprintf(buf, sizeof buf, "ODEFunc n=%d depth %d width %d: no kernel instantiated (need n+m<=4, 3 hidden)",
+    if (ok && d->n == 4 && hid == 128) return V_ODE_4_128;
+    snprintf(buf, sizeof buf, "ODEFunc n=%d depth %d width %d: no kernel instantiated (have n=2,3,4 width 128; n=2 width 64; 3 hidden)",
              d->n, d->h_net.depth, hid);
     *why = buf;
     return V_NONE;
@@ -420,8 +424,14 @@ void pack_ode(std::vector<float>& img, const phnn_desc* d, const float* p) {
   pack_rows(img.data() + M::oW4r, W4, N, HID, M::LR);
   memcpy(img.data() + M::oB4, b4, sizeof(float) * N);
   pack_in_frag_T<HID>(img.data() + M::oW4f, W4, N);
-  pack_cols_as_rows(img.data() + M::oW1T, W1, HID, nin, M::LR);
+  for (int r = 0; r < HID; ++r)
+    for (int c = 0; c < nin && c < 4; ++c) img[M::oW1T + (size_t)c * M::LR + r] = W1[(size_t)r * nin + c];
   for (int k = 0; k < 4 * M::LR; ++k) img[M::oW1T + k] /= (S2 * S3);
+  if (M::WIDE) {  // control column of W1: second k-step fragment (k-slot q = 0) and its replicated-row image
+    for (int nt = 0; nt < HID / 16; ++nt)
+      for (int lane = 0; lane < 16; ++lane) img[M::oW1fu + nt * 64 + lane] = W1[(size_t)(16 * nt + lane) * nin + N];
+    for (int r = 0; r < HID; ++r) img[M::oW1Tu + r] = W1[(size_t)r * nin + N] / (S2 * S3);
+  }
   img[M::oSC + 0] = 2.8853900817779268f / S2;
   img[M::oSC + 1] = 2.8853900817779268f / S3;
 }
@@ -443,6 +453,7 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_CANON_128_H: pack_canon<M_CANON_128_H>(img, d, blob); break;
     case V_ODE_2_128_H: pack_ode<M_ODE_2_128_H>(img, d, blob); break;
     case V_ODE_3_128_H: pack_ode<M_ODE_3_128_H>(img, d, blob); break;
+    case V_ODE_4_128: pack_ode<M_ODE_4_128>(img, d, blob); break;
     default: break;
   }
 }

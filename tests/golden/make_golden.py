@@ -239,6 +239,19 @@ def main():
                       xlo_p, -xlo_p, 2.5, 404, CASES)
     np.savez(os.path.join(OUT, "golden_odefunc_pendulum.npz"), **blk)
 
+    # the reference's DEFAULT ODEFunc: state_dim=4, action_dim=1 (cart-pole), same treatment
+    torch.manual_seed(0)
+    ode4 = ODEFunc(4, 1)
+    with torch.no_grad():
+        g4 = torch.Generator().manual_seed(2)
+        for mod in ode4.modules():
+            if isinstance(mod, nn.Linear):
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g4))
+    np.savez(os.path.join(OUT, "weights_odefunc_cartpole.npz"), **sd_numpy(ode4))
+    blk = model_block("odefunc_cartpole", OdeAdapter(ode4), 4, 1, 0.02, Qc, Rc, np.zeros(4), -15.0, 15.0,
+                      xlo_c, xhi_c, 5.0, 505, CASES)
+    np.savez(os.path.join(OUT, "golden_odefunc_cartpole.npz"), **blk)
+
     # ------------------------------------------------------------------ G5 / G6 / G9 controllers
     ctl = {}
     mpc = cfg["mpc"]

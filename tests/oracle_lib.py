@@ -123,7 +123,7 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-MODELS = ["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum"]
+MODELS = ["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum", "odefunc_cartpole"]
 
 
 def cost_from_golden(g, n=None, m=None, Q=None, x_target=None):

@@ -38,7 +38,8 @@ def npy(t):
     return t.detach().cpu().numpy().astype(np.float64)
 
 
-TRAJ_ATOL = {"phnn_cartpole": 1e-5, "canonical_cartpole": 1e-5, "phnn_pendulum": 5e-5, "odefunc_pendulum": 5e-5}
+TRAJ_ATOL = {"phnn_cartpole": 1e-5, "canonical_cartpole": 1e-5, "phnn_pendulum": 5e-5, "odefunc_pendulum": 5e-5,
+             "odefunc_cartpole": 1e-5}
 
 
 def assert_rollout_close(cost, traj, gu, gx0, ref_cost, ref_traj, ref_gu, ref_gx0, traj_atol=1e-5):
