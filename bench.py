@@ -77,13 +77,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PHNN_BENCH_BACKEND=gloo lets the N>1 flow be rehearsed with several ranks on ONE GPU (RCCL refuses two ranks
+    # on a device); the driver's runs use the default, nccl (= RCCL) with one GPU per rank.
+    backend = os.environ.get("PHNN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
 
     from phnn_mpc_amd import _capi
     from phnn_mpc_amd.engine import RolloutEngine
@@ -115,7 +122,12 @@ def main():
         if ev is not None:
             ev[2].record()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, c)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, c)
+            else:  # rehearsal backend: collectives on host copies
+                parts = [torch.empty(B, dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(parts, c.cpu())
+                gathered.copy_(torch.cat(parts))
         return c
 
     import ctypes as C
@@ -143,7 +155,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     k1_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
