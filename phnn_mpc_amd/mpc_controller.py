@@ -75,15 +75,42 @@ class MPCController:
         """current_state (n,) -> optimal first control, np.ndarray (1,)   (src/mpc_controller.py:143-209)"""
         if isinstance(current_state, np.ndarray):
             current_state = torch.tensor(current_state, dtype=torch.float32)
+        if self.optimizer_type == "LBFGS":
+            return self._compute_control_lbfgs(current_state)
         u = self.compute_control_batch(current_state.reshape(1, -1))
         return u[0]
+
+    def _compute_control_lbfgs(self, current_state):
+        """The reference's L-BFGS branch (src/mpc_controller.py:169-170,196-197): torch.optim.LBFGS(lr, max_iter=20)
+        stepped max_iterations times; the closure's cost and gradient come from K1/K2 instead of autograd.  One
+        plant at a time (L-BFGS keeps a curvature history per problem)."""
+        eng = self.engine
+        x0 = current_state.reshape(1, -1).to(eng.device, torch.float32)
+        control_sequence = torch.zeros(self.horizon, 1, requires_grad=True)
+        optimizer = torch.optim.LBFGS([control_sequence], lr=self.lr, max_iter=20)
+        cost_struct, ws = self._cost(), {}
+
+        def closure():
+            optimizer.zero_grad()
+            c, g = eng.rollout_cost_grad(x0, control_sequence.detach().reshape(1, self.horizon, 1).to(eng.device), cost_struct,
+                                         self.integrator, self.dt, workspace=ws)
+            control_sequence.grad = g.reshape(self.horizon, 1).to(control_sequence.device).clone()
+            return c.reshape(()).to(control_sequence.device).clone()
+
+        for _ in range(self.max_iterations):
+            optimizer.step(closure)
+        with torch.no_grad():
+            u0 = control_sequence[0]
+            if self.u_min is not None and self.u_max is not None:
+                u0 = torch.clamp(u0, self.u_min, self.u_max)
+        return u0.detach().numpy()
 
     # ------------------------------------------------------------------ batched (new)
     def solve_batch(self, states, record_costs=False):
         """states (B,n) -> dict with the last iterate of B independent problems (all on the engine's device)."""
         if self.optimizer_type == "LBFGS":
-            raise NotImplementedError("the L-BFGS branch (src/mpc_controller.py:169-170) is not selected by any "
-                                      "script of the reference and has no kernel")
+            raise NotImplementedError("L-BFGS keeps a curvature history per problem: use compute_control (one plant "
+                                      "at a time); the batched solve is Adam only")
         if self.optimizer_type != "Adam":
             raise ValueError(f"Unknown optimizer type: {self.optimizer_type}")
         eng = self.engine

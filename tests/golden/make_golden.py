@@ -22,6 +22,7 @@ Vector sets:
   G10 reverse pass with trajectory + cost cotangents golden_<model>.npz  tvjp_*
   G11 the NumPy plant CartPoleSimulator.step         golden_controllers.npz  plant_*
   G12 coordinate transforms with the cart-pole M_net golden_controllers.npz  ct_*
+  G13 MPCController with optimizer_type="LBFGS"      golden_controllers.npz  lbfgs_*
 Each quantity is stored twice: *_f64 from the reference cast to double, *_f32 from the
 reference as shipped (float32, torch CPU).
 """
@@ -302,6 +303,10 @@ def main():
     ctl["bar_xmin"], ctl["bar_xmax"], ctl["bar_u"] = np.asarray(xmin), np.asarray(xmax), ub
     ctl["bar_cost"], ctl["bar_grad"], ctl["bar_states"] = np.float32(cost.item()), ubt.grad.numpy().copy(), st.detach().numpy()
     ctl["bar_u0_after5"] = np.asarray(cb.compute_control(x_init.copy()))
+    # G13: the L-BFGS branch of MPCController (src/mpc_controller.py:169-170,196-197), 3 outer iterations
+    cl = MPCController(phnn_model=phnn, horizon=20, dt=0.02, Q=mpc["Q_diag"], R=0.01, target_state=mpc["x_target"],
+                       u_min=-15.0, u_max=15.0, optimizer_type="LBFGS", lr=0.5, max_iterations=3)
+    ctl["lbfgs_u0"] = np.asarray(cl.compute_control(x_init.copy()))
     # G11: the reference plant (src/cartpole_simulator.py:63-112), 3 plants x 60 steps of seeded forces
     from cartpole_simulator import CartPoleSimulator
     rngp = np.random.default_rng(12)

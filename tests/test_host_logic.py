@@ -295,3 +295,14 @@ def test_coordinate_transforms_match_reference_g12(ctl):
     q, v = CT.split_state(y)
     assert q.shape == (32, 2) and v.shape == (32, 2)
     assert m.M_net.get_parameters_dict().keys() == {"a", "b", "c"}
+
+
+def test_lbfgs_branch_matches_reference_g13(ctl):
+    """optimizer_type='LBFGS' (src/mpc_controller.py:169-170): torch's L-BFGS driven by the engine's cost/gradient."""
+    c = MPCController(phnn_model=_phnn_with_oracle(), horizon=20, dt=0.02, Q=[10.0, 200.0, 1.0, 10.0], R=0.01,
+                      target_state=[0.0, 0.0, 0.0, 0.0], u_min=-15.0, u_max=15.0, optimizer_type="LBFGS", lr=0.5,
+                      max_iterations=3)
+    u0 = c.compute_control(ctl["mpc_x0"].copy())
+    assert u0.shape == (1,) and abs(u0[0] - ctl["lbfgs_u0"][0]) < 5e-4 * max(1.0, abs(ctl["lbfgs_u0"][0])), (u0, ctl["lbfgs_u0"])
+    with pytest.raises(NotImplementedError):
+        c.compute_control_batch(ctl["mpc_x0"][None])
