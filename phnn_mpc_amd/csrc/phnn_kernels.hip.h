@@ -447,14 +447,19 @@ DEV void sq_bwd_h(Act<T>& o, const float* Wimg, Lane ln, const Split2<T>& in) {
   matrix_phase_end();
 }
 
-// 16*TI units -> 4 outputs, every lane receives all 4 (row 4q+r of the MFMA tile carries output r).
-// Wt is [4][LR], LR = 16*TI + 8, row c = weights of output c.
+// 16*TI units -> 4 outputs, every lane receives all 4.  Wt is [4][LR], LR = 16*TI + 8, row c = weights of output c.
+// Uses the 16-block v_mfma_f32_4x4x1 (8 cycles): block b = lane>>2 = 4q + (i>>2) multiplies A_b[c][0] = Wt[c = i&3]
+// [unit 16t+4q+r] with B_b[0][j = i&3] = the accumulator value of rollout i, i.e. one k per k-slot q and a group of
+// four rollouts per block -- exactly the register contents we have.  Each lane then holds, in register c, output c of
+// its rollout summed over ITS k-slot's units; the four k-slots are added with two cross-lane steps.  32 MFMAs x 8
+// cycles + 8 shuffles instead of 32 MFMAs x 32 cycles for the replicated-row 16x16x4 form (PHNN_TO4_REP selects it).
 template <int TI>
 DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
   constexpr int LR = 16 * TI + 8;
   keep_lds_reads_local();
   const float* base = Wt + (ln.i & 3) * LR + 4 * ln.q;
   f32x4 o0 = splat4(0.f), o1 = splat4(0.f);
+#ifdef PHNN_TO4_REP
 #pragma unroll
   for (int t = 0; t < TI; ++t) {
     f32x4 a = *reinterpret_cast<const f32x4*>(base + 16 * t);
@@ -465,6 +470,26 @@ DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
     }
   }
   return o0 + o1;
+#else
+#pragma unroll
+  for (int t = 0; t < TI; ++t) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(base + 16 * t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if ((r & 1) == 0) o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], in.v[t][r], o0, 0, 0, 0);
+      else o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], in.v[t][r], o1, 0, 0, 0);
+    }
+  }
+  f32x4 o = o0 + o1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v = o[c];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    o[c] = v;
+  }
+  return o;
+#endif
 }
 
 // Per-wave stash in HBM (K1 -> K2): one activation vector = T x 64 lanes x float4, i.e. one fully coalesced
