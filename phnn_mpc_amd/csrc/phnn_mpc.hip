@@ -3,6 +3,7 @@
 // point either launches a gfx950 kernel or returns an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
@@ -375,6 +376,82 @@ void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
     for (int i = 0; i < N; ++i) img[M::oG + i] = G[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Width padding: kernels exist for hidden widths 64 and 128.  Any narrower MLP is embedded EXACTLY by adding
+// hidden units with zero weights and zero bias (tanh(0) = 0 feeds zero weights; their (1 - a^2) factors multiply
+// zero back-propagated signals), so e.g. H_mlp [96, 80] + R_mlp [48] runs on the 128-wide kernels.
+// ---------------------------------------------------------------------------------------------
+const float* pad_mlp(std::vector<float>& out, const float* p, const phnn_mlp_shape& s, int in, int outdim, int W) {
+  int last = in, last_p = in;
+  for (int l = 0; l <= s.depth; ++l) {
+    int o = l < s.depth ? s.hidden[l] : outdim, o_p = l < s.depth ? W : outdim;
+    size_t base = out.size();
+    out.resize(base + (size_t)o_p * last_p + o_p, 0.f);
+    for (int r = 0; r < o; ++r)
+      for (int c = 0; c < last; ++c) out[base + (size_t)r * last_p + c] = p[(size_t)r * last + c];
+    p += (size_t)o * last;
+    for (int r = 0; r < o; ++r) out[base + (size_t)o_p * last_p + r] = p[r];
+    p += o;
+    last = o;
+    last_p = o_p;
+  }
+  return p;
+}
+
+int max_hidden(const phnn_mlp_shape& s) {
+  int m = 0;
+  for (int l = 0; l < s.depth; ++l) m = s.hidden[l] > m ? s.hidden[l] : m;
+  return m;
+}
+
+// -> padded description + blob (or the originals when nothing needs padding); false with a reason when no width fits
+bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector<float>* pblob, std::string* why) {
+  *pd = *d;
+  int mx = max_hidden(d->h_net);
+  if (d->kind == PHNN_MODEL_PHNN) {
+    mx = std::max(mx, max_hidden(d->r_net));
+    if (!d->fixed_G) mx = std::max(mx, max_hidden(d->g_net));
+  }
+  // widths with a kernel for this family (pick_variant)
+  int W = 0;
+  if (d->kind == PHNN_MODEL_PHNN) W = d->n == 4 ? (mx <= 64 ? 64 : 128) : 64;
+  else if (d->kind == PHNN_MODEL_CANONICAL) W = mx <= 64 ? 64 : 128;
+  else W = (d->n == 2 && mx <= 64) ? 64 : 128;
+  if (mx > W || mx < 1) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "hidden width %d exceeds the widest kernel (%d) for this model family / state dimension", mx, W);
+    *why = buf;
+    return false;
+  }
+  auto set_w = [&](phnn_mlp_shape& s) {
+    for (int l = 0; l < s.depth; ++l) s.hidden[l] = W;
+  };
+  int n = d->n, m = d->m;
+  const float* p = blob;
+  pblob->clear();
+  if (d->kind == PHNN_MODEL_PHNN) {
+    size_t head = (size_t)n * n + (d->fixed_G ? (size_t)n * m : 0);
+    pblob->assign(p, p + head);
+    p += head;
+    p = pad_mlp(*pblob, p, d->r_net, n, n * n, W);
+    p = pad_mlp(*pblob, p, d->h_net, n, 1, W);
+    if (!d->fixed_G) p = pad_mlp(*pblob, p, d->g_net, n, n * m, W);
+    set_w(pd->r_net);
+    set_w(pd->h_net);
+    if (!d->fixed_G) set_w(pd->g_net);
+  } else if (d->kind == PHNN_MODEL_CANONICAL) {
+    size_t head = (size_t)n + (size_t)n * m + 3;
+    pblob->assign(p, p + head);
+    p += head;
+    p = pad_mlp(*pblob, p, d->h_net, n, 1, W);
+    set_w(pd->h_net);
+  } else {
+    p = pad_mlp(*pblob, p, d->h_net, n + m, n, W);
+    set_w(pd->h_net);
+  }
+  return true;
+}
+
 float softplus_host(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 template <class M>
@@ -551,7 +628,10 @@ int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_float
     return fail(nullptr, PHNN_ERR_INVALID_ARG, buf);
   }
   std::string why;
-  int v = pick_variant(desc, &why);
+  phnn_desc pdesc;
+  std::vector<float> pblob;
+  if (!pad_model(desc, weights_host, &pdesc, &pblob, &why)) return fail(nullptr, PHNN_ERR_UNSUPPORTED, why);
+  int v = pick_variant(&pdesc, &why);
   if (v == V_NONE) return fail(nullptr, PHNN_ERR_UNSUPPORTED, why);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -569,7 +649,7 @@ int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_float
   e = hipGetDeviceProperties(&prop, device);
   h->n_cu = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   std::vector<float> img;
-  pack_image(v, img, desc, weights_host);
+  pack_image(v, img, &pdesc, pblob.data());
   e = hipMalloc(reinterpret_cast<void**>(&h->d_img), sizeof(float) * img.size());
   if (e != hipSuccess) {
     delete h;

@@ -240,6 +240,22 @@ def main():
                       xlo_p, -xlo_p, 2.5, 404, CASES)
     np.savez(os.path.join(OUT, "golden_odefunc_pendulum.npz"), **blk)
 
+    # a pHNN with hidden widths no kernel is instantiated for (H_mlp [96, 80], R_mlp [48]): the engine embeds it
+    # exactly in the 128-wide kernels by zero padding
+    import tempfile
+    cfg_odd = yaml.safe_load(open("cartpole_mpc_config.yaml"))
+    cfg_odd["model"]["H_mlp"]["hidden_sizes"] = [96, 80]
+    cfg_odd["model"]["R_mlp"]["hidden_sizes"] = [48]
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as tf:
+        yaml.safe_dump(cfg_odd, tf)
+    torch.manual_seed(3)
+    phnn_odd = pHNN(tf.name)
+    os.unlink(tf.name)
+    np.savez(os.path.join(OUT, "weights_phnn_cartpole_odd.npz"), **sd_numpy(phnn_odd))
+    blk = model_block("phnn_cartpole_odd", phnn_odd, 4, 1, 0.02, Qc, Rc, np.zeros(4), -15.0, 15.0,
+                      xlo_c, xhi_c, 5.0, 606, CASES)
+    np.savez(os.path.join(OUT, "golden_phnn_cartpole_odd.npz"), **blk)
+
     # the reference's DEFAULT ODEFunc: state_dim=4, action_dim=1 (cart-pole), same treatment
     torch.manual_seed(0)
     ode4 = ODEFunc(4, 1)

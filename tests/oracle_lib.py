@@ -123,7 +123,8 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-MODELS = ["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum", "odefunc_cartpole"]
+MODELS = ["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum", "odefunc_cartpole",
+          "phnn_cartpole_odd"]  # _odd: hidden widths [96, 80] / [48], zero-padded by the engine to the 128-wide kernels
 
 
 def cost_from_golden(g, n=None, m=None, Q=None, x_target=None):

@@ -39,7 +39,7 @@ def npy(t):
 
 
 TRAJ_ATOL = {"phnn_cartpole": 1e-5, "canonical_cartpole": 1e-5, "phnn_pendulum": 5e-5, "odefunc_pendulum": 5e-5,
-             "odefunc_cartpole": 1e-5}
+             "odefunc_cartpole": 1e-5, "phnn_cartpole_odd": 1e-5}
 
 
 def assert_rollout_close(cost, traj, gu, gx0, ref_cost, ref_traj, ref_gu, ref_gx0, traj_atol=1e-5):
@@ -173,12 +173,19 @@ def test_errors(torch_cuda):
     g = ol.load_golden("phnn_cartpole")
     with pytest.raises(ValueError):
         eng.rollout_cost(g["fwd_x"][:4], np.zeros((4, 5, 1)), ol.cost_from_golden(g), "leapfrog", 0.02)
-    bad = dict(w)
-    bad["H_net.net.2.weight"] = np.zeros((96, 128), np.float32)
-    bad["H_net.net.2.bias"] = np.zeros(96, np.float32)
-    bad["H_net.net.4.weight"] = np.zeros((1, 96), np.float32)
-    with pytest.raises(PhnnError):
+    bad = dict(w)  # narrower layers are zero-padded to a kernel width; wider than 128 has no kernel
+    bad["H_net.net.2.weight"] = np.zeros((160, 128), np.float32)
+    bad["H_net.net.2.bias"] = np.zeros(160, np.float32)
+    bad["H_net.net.4.weight"] = np.zeros((1, 160), np.float32)
+    with pytest.raises(PhnnError, match="exceeds the widest kernel"):
         RolloutEngine(bad)
+    deep = dict(w)  # a third hidden layer in R_net: no kernel
+    deep["R_net.net.2.weight"] = np.zeros((128, 128), np.float32)
+    deep["R_net.net.2.bias"] = np.zeros(128, np.float32)
+    deep["R_net.net.4.weight"] = np.zeros((16, 128), np.float32)
+    deep["R_net.net.4.bias"] = np.zeros(16, np.float32)
+    with pytest.raises(PhnnError):
+        RolloutEngine(deep)
 
 
 def test_stash_and_recompute_modes_agree(bundle):
