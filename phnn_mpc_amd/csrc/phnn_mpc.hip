@@ -36,6 +36,9 @@ enum Variant {
   V_ODE_2_128_H,
   V_ODE_3_128_H,
   V_ODE_4_128,  // the reference's default ODEFunc(4,1): 5 inputs; f32 only (the f16x2 image would not fit LDS)
+  V_PHNN_4_128_GNET_H,  // remaining (n, G) combinations at width 128, f16x2 only
+  V_PHNN_2_128_GNET_H,
+  V_PHNN_2_128_FIX_H,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -54,6 +57,9 @@ using M_CANON_128_H = CanonModel<128, MM_F16X2>;
 using M_ODE_2_128_H = OdeModel<2, 128, MM_F16X2>;
 using M_ODE_3_128_H = OdeModel<3, 128, MM_F16X2>;
 using M_ODE_4_128 = OdeModel<4, 128>;
+using M_PHNN_4_128_GNET_H = PhnnModel<4, 128, false, MM_F16X2>;
+using M_PHNN_2_128_GNET_H = PhnnModel<2, 128, false, MM_F16X2>;
+using M_PHNN_2_128_FIX_H = PhnnModel<2, 128, true, MM_F16X2>;
 
 struct KernelSet {
   void (*fwd[2])(RollParams);
@@ -104,6 +110,9 @@ bool kernel_set(int v, KernelSet* k) {
     case V_ODE_2_128_H: *k = make_set<M_ODE_2_128_H>("odefunc<n=2,hid=128,f16x2>"); return true;
     case V_ODE_3_128_H: *k = make_set<M_ODE_3_128_H>("odefunc<n=3,hid=128,f16x2>"); return true;
     case V_ODE_4_128: *k = make_set<M_ODE_4_128>("odefunc<n=4,hid=128>"); return true;
+    case V_PHNN_4_128_GNET_H: *k = make_set<M_PHNN_4_128_GNET_H>("phnn<n=4,hid=128,Gnet,f16x2>"); return true;
+    case V_PHNN_2_128_GNET_H: *k = make_set<M_PHNN_2_128_GNET_H>("phnn<n=2,hid=128,Gnet,f16x2>"); return true;
+    case V_PHNN_2_128_FIX_H: *k = make_set<M_PHNN_2_128_FIX_H>("phnn<n=2,hid=128,fixedG,f16x2>"); return true;
     default: return false;
   }
 }
@@ -179,9 +188,11 @@ int pick_variant(const phnn_desc* d, std::string* why) {
     if (ok && d->n == 4 && hid == 64 && d->fixed_G) return V_PHNN_4_64_FIX;
     if (ok && d->n == 2 && hid == 64 && !d->fixed_G) return V_PHNN_2_64_GNET;
     if (ok && d->n == 2 && hid == 64 && d->fixed_G) return V_PHNN_2_64_FIX;
+    if (ok && d->n == 4 && hid == 128 && !d->fixed_G) return V_PHNN_4_128_GNET_H;
+    if (ok && d->n == 2 && hid == 128) return d->fixed_G ? V_PHNN_2_128_FIX_H : V_PHNN_2_128_GNET_H;
     snprintf(buf, sizeof buf,
              "pHNN n=%d H_net depth %d width %d / R_net depth %d width %d fixed_G=%d: no kernel instantiated "
-             "(have n=4 hid 128|64 fixed G; n=2 hid 64 fixed or learned G; all nets one shared width)",
+             "(have n=2|4, fixed or learned G, hidden widths up to 128, H_net 2 hidden layers, R_net/G_net 1)",
              d->n, d->h_net.depth, hid, d->r_net.depth, d->r_net.hidden[0], d->fixed_G);
     *why = buf;
     return V_NONE;
@@ -414,7 +425,7 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
   }
   // widths with a kernel for this family (pick_variant)
   int W = 0;
-  if (d->kind == PHNN_MODEL_PHNN) W = d->n == 4 ? (mx <= 64 ? 64 : 128) : 64;
+  if (d->kind == PHNN_MODEL_PHNN) W = (mx <= 64 && (d->fixed_G || d->n == 2)) ? 64 : 128;
   else if (d->kind == PHNN_MODEL_CANONICAL) W = mx <= 64 ? 64 : 128;
   else W = (d->n == 2 && mx <= 64) ? 64 : 128;
   if (mx > W || mx < 1) {
@@ -531,6 +542,9 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_ODE_2_128_H: pack_ode<M_ODE_2_128_H>(img, d, blob); break;
     case V_ODE_3_128_H: pack_ode<M_ODE_3_128_H>(img, d, blob); break;
     case V_ODE_4_128: pack_ode<M_ODE_4_128>(img, d, blob); break;
+    case V_PHNN_4_128_GNET_H: pack_phnn<M_PHNN_4_128_GNET_H>(img, d, blob); break;
+    case V_PHNN_2_128_GNET_H: pack_phnn<M_PHNN_2_128_GNET_H>(img, d, blob); break;
+    case V_PHNN_2_128_FIX_H: pack_phnn<M_PHNN_2_128_FIX_H>(img, d, blob); break;
     default: break;
   }
 }

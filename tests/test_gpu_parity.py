@@ -265,3 +265,52 @@ def test_f16x2_scaling_with_extreme_weights(torch_cuda):
     rdx, rH = m64.forward(g["fwd_x"], g["fwd_u"])
     assert np.abs(npy(dx) - rdx).max() <= 3e-5 * np.abs(rdx).max()
     assert np.abs(npy(H) - rH).max() <= 3e-5 * np.abs(rH).max()
+
+
+def _random_phnn_weights(rng, n, m, hH, hR, hG):
+    """state_dict-shaped random weights for a pHNN with the given hidden sizes (hG None -> fixed G)."""
+    def lin(o, i):
+        b = 1.0 / np.sqrt(i)
+        return rng.uniform(-b, b, size=(o, i)).astype(np.float32), rng.uniform(-b, b, size=(o,)).astype(np.float32)
+    w = {"J": rng.normal(size=(n, n)).astype(np.float32)}
+    dims = [n] + list(hH) + [1]
+    for k in range(len(dims) - 1):
+        w[f"H_net.net.{2 * k}.weight"], w[f"H_net.net.{2 * k}.bias"] = lin(dims[k + 1], dims[k])
+    dims = [n] + list(hR) + [n * n]
+    for k in range(len(dims) - 1):
+        w[f"R_net.net.{2 * k}.weight"], w[f"R_net.net.{2 * k}.bias"] = lin(dims[k + 1], dims[k])
+    if hG is None:
+        w["G_fixed"] = rng.normal(size=(n, m)).astype(np.float32)
+    else:
+        dims = [n] + list(hG) + [n * m]
+        for k in range(len(dims) - 1):
+            w[f"G_net.net.{2 * k}.weight"], w[f"G_net.net.{2 * k}.bias"] = lin(dims[k + 1], dims[k])
+    return w
+
+
+@pytest.mark.parametrize("shape", [(4, (100, 128), (72,), (90,)), (2, (128, 96), (128,), (80,)), (2, (70, 65), (33,), None),
+                                   (4, (40, 64), (64,), None), (2, (24, 48), (16,), (20,))])
+def test_other_phnn_shapes_vs_oracle(torch_cuda, shape):
+    """(n, G fixed|learned, hidden widths) combinations beyond the shipped configs -- zero-padded to a kernel width --
+    against the float64 oracle (which is pinned to the reference on the shipped shapes and generic in the sizes)."""
+    from phnn_mpc_amd import _capi
+    from phnn_mpc_amd.engine import RolloutEngine
+    n, hH, hR, hG = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    w = _random_phnn_weights(rng, n, 1, hH, hR, hG)
+    eng, m64 = RolloutEngine(w), ol.OracleModel(w, "f64")
+    x = (rng.uniform(-1, 1, size=(40, n)) * 0.8).astype(np.float32)
+    u = rng.uniform(-2, 2, size=(40, 1)).astype(np.float32)
+    lam = rng.normal(size=(40, n)).astype(np.float32)
+    dx, H = eng.forward(x, u)
+    rdx, rH = m64.forward(x, u)
+    assert np.abs(npy(dx) - rdx).max() <= 2e-5 * np.abs(rdx).max() and np.abs(npy(H) - rH).max() <= 2e-5 * max(1.0, np.abs(rH).max())
+    xb, ub = eng.vjp(x, u, lam)
+    rxb, rub = m64.vjp(x, u, lam)
+    assert np.abs(npy(xb) - rxb).max() <= 3e-5 * np.abs(rxb).max() and np.abs(npy(ub) - rub).max() <= 3e-5 * np.abs(rub).max()
+    cost = _capi.make_cost(n, 1, np.linspace(1.0, 5.0, n), [0.02], None, -3.0, 3.0)
+    x0, U = x[:33] * 0.5, rng.uniform(-4, 4, size=(33, 25, 1)).astype(np.float32)
+    for integ in ("euler", "rk4"):
+        ref = m64.rollout(x0, U, cost, integ, 0.01, nthreads=8)
+        c, gu, gx = eng.rollout_cost_grad(x0, U, cost, integ, 0.01, want_grad_x0=True)
+        assert_rollout_close(npy(c), None, npy(gu), npy(gx), ref["cost"], None, ref["grad_u"], ref["grad_x0"])
