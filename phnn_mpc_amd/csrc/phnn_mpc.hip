@@ -39,6 +39,11 @@ enum Variant {
   V_PHNN_4_128_GNET_H,  // remaining (n, G) combinations at width 128, f16x2 only
   V_PHNN_2_128_GNET_H,
   V_PHNN_2_128_FIX_H,
+  V_PHNN_4_64_FIX_H,  // f16x2 forms of the 64-wide models
+  V_PHNN_2_64_GNET_H,
+  V_PHNN_2_64_FIX_H,
+  V_CANON_64_H,
+  V_ODE_2_64_H,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -60,6 +65,11 @@ using M_ODE_4_128 = OdeModel<4, 128>;
 using M_PHNN_4_128_GNET_H = PhnnModel<4, 128, false, MM_F16X2>;
 using M_PHNN_2_128_GNET_H = PhnnModel<2, 128, false, MM_F16X2>;
 using M_PHNN_2_128_FIX_H = PhnnModel<2, 128, true, MM_F16X2>;
+using M_PHNN_4_64_FIX_H = PhnnModel<4, 64, true, MM_F16X2>;
+using M_PHNN_2_64_GNET_H = PhnnModel<2, 64, false, MM_F16X2>;
+using M_PHNN_2_64_FIX_H = PhnnModel<2, 64, true, MM_F16X2>;
+using M_CANON_64_H = CanonModel<64, MM_F16X2>;
+using M_ODE_2_64_H = OdeModel<2, 64, MM_F16X2>;
 
 struct KernelSet {
   void (*fwd[2])(RollParams);
@@ -113,6 +123,11 @@ bool kernel_set(int v, KernelSet* k) {
     case V_PHNN_4_128_GNET_H: *k = make_set<M_PHNN_4_128_GNET_H>("phnn<n=4,hid=128,Gnet,f16x2>"); return true;
     case V_PHNN_2_128_GNET_H: *k = make_set<M_PHNN_2_128_GNET_H>("phnn<n=2,hid=128,Gnet,f16x2>"); return true;
     case V_PHNN_2_128_FIX_H: *k = make_set<M_PHNN_2_128_FIX_H>("phnn<n=2,hid=128,fixedG,f16x2>"); return true;
+    case V_PHNN_4_64_FIX_H: *k = make_set<M_PHNN_4_64_FIX_H>("phnn<n=4,hid=64,fixedG,f16x2>"); return true;
+    case V_PHNN_2_64_GNET_H: *k = make_set<M_PHNN_2_64_GNET_H>("phnn<n=2,hid=64,Gnet,f16x2>"); return true;
+    case V_PHNN_2_64_FIX_H: *k = make_set<M_PHNN_2_64_FIX_H>("phnn<n=2,hid=64,fixedG,f16x2>"); return true;
+    case V_CANON_64_H: *k = make_set<M_CANON_64_H>("canonical<hid=64,f16x2>"); return true;
+    case V_ODE_2_64_H: *k = make_set<M_ODE_2_64_H>("odefunc<n=2,hid=64,f16x2>"); return true;
     default: return false;
   }
 }
@@ -160,14 +175,17 @@ bool same_hidden(const phnn_mlp_shape& s, int depth, int hid) {
 
 // How the hidden x hidden products are evaluated where a variant exists: PHNN_MATMUL = f32 | bf16x3 | f16x2
 // (tools/probe_bf16_split.hip).  Default: kDefaultMatmul.
-constexpr int kDefaultMatmul = MM_F16X2;
-int matmul_mode() {
+// Default: f16x2 for the 128-wide kernels (the products dominate there; cart-pole parity margins 0.1 of the
+// tolerance), all-f32 for the 64-wide ones (little to gain, and the trained pendulum model -- long, large-amplitude
+// swings -- uses 0.9 of the cost tolerance with f32 products already and 1.2 with f16x2 in a 100-step stress case).
+int matmul_mode(int hid = 128) {
+  const int dflt = hid >= 128 ? MM_F16X2 : MM_F32;
   const char* e = getenv("PHNN_MATMUL");
-  if (!e) return kDefaultMatmul;
+  if (!e) return dflt;
   if (strcmp(e, "f32") == 0) return MM_F32;
   if (strcmp(e, "bf16x3") == 0) return MM_BF16X3;
   if (strcmp(e, "f16x2") == 0) return MM_F16X2;
-  return kDefaultMatmul;
+  return dflt;
 }
 
 int pick_variant(const phnn_desc* d, std::string* why) {
@@ -185,9 +203,10 @@ int pick_variant(const phnn_desc* d, std::string* why) {
       int mm = matmul_mode();
       return mm == MM_F16X2 ? V_PHNN_4_128_FIX_H : (mm == MM_BF16X3 ? V_PHNN_4_128_FIX_BF : V_PHNN_4_128_FIX);
     }
-    if (ok && d->n == 4 && hid == 64 && d->fixed_G) return V_PHNN_4_64_FIX;
-    if (ok && d->n == 2 && hid == 64 && !d->fixed_G) return V_PHNN_2_64_GNET;
-    if (ok && d->n == 2 && hid == 64 && d->fixed_G) return V_PHNN_2_64_FIX;
+    const bool h16 = matmul_mode(hid) == MM_F16X2;
+    if (ok && d->n == 4 && hid == 64 && d->fixed_G) return h16 ? V_PHNN_4_64_FIX_H : V_PHNN_4_64_FIX;
+    if (ok && d->n == 2 && hid == 64 && !d->fixed_G) return h16 ? V_PHNN_2_64_GNET_H : V_PHNN_2_64_GNET;
+    if (ok && d->n == 2 && hid == 64 && d->fixed_G) return h16 ? V_PHNN_2_64_FIX_H : V_PHNN_2_64_FIX;
     if (ok && d->n == 4 && hid == 128 && !d->fixed_G) return V_PHNN_4_128_GNET_H;
     if (ok && d->n == 2 && hid == 128) return d->fixed_G ? V_PHNN_2_128_FIX_H : V_PHNN_2_128_GNET_H;
     snprintf(buf, sizeof buf,
@@ -203,7 +222,7 @@ int pick_variant(const phnn_desc* d, std::string* why) {
       int mm = matmul_mode();
       return mm == MM_F16X2 ? V_CANON_128_H : (mm == MM_BF16X3 ? V_CANON_128_BF : V_CANON_128);
     }
-    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 64) return V_CANON_64;
+    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 64) return matmul_mode(64) == MM_F16X2 ? V_CANON_64_H : V_CANON_64;
     snprintf(buf, sizeof buf, "canonical pHNN n=%d H_net depth %d width %d: no kernel instantiated", d->n,
              d->h_net.depth, hid);
     *why = buf;
@@ -213,7 +232,7 @@ int pick_variant(const phnn_desc* d, std::string* why) {
     int hid = d->h_net.hidden[0];
     bool ok = same_hidden(d->h_net, 3, hid);
     if (ok && d->n == 2 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_2_128_H : V_ODE_2_128;
-    if (ok && d->n == 2 && hid == 64) return V_ODE_2_64;
+    if (ok && d->n == 2 && hid == 64) return matmul_mode(64) == MM_F16X2 ? V_ODE_2_64_H : V_ODE_2_64;
     if (ok && d->n == 3 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_3_128_H : V_ODE_3_128;
     if (ok && d->n == 4 && hid == 128) return V_ODE_4_128;
     snprintf(buf, sizeof buf, "ODEFunc n=%d depth %d width %d: no kernel instantiated (have n=2,3,4 width 128; n=2 width 64; 3 hidden)",
@@ -545,6 +564,11 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_PHNN_4_128_GNET_H: pack_phnn<M_PHNN_4_128_GNET_H>(img, d, blob); break;
     case V_PHNN_2_128_GNET_H: pack_phnn<M_PHNN_2_128_GNET_H>(img, d, blob); break;
     case V_PHNN_2_128_FIX_H: pack_phnn<M_PHNN_2_128_FIX_H>(img, d, blob); break;
+    case V_PHNN_4_64_FIX_H: pack_phnn<M_PHNN_4_64_FIX_H>(img, d, blob); break;
+    case V_PHNN_2_64_GNET_H: pack_phnn<M_PHNN_2_64_GNET_H>(img, d, blob); break;
+    case V_PHNN_2_64_FIX_H: pack_phnn<M_PHNN_2_64_FIX_H>(img, d, blob); break;
+    case V_CANON_64_H: pack_canon<M_CANON_64_H>(img, d, blob); break;
+    case V_ODE_2_64_H: pack_ode<M_ODE_2_64_H>(img, d, blob); break;
     default: break;
   }
 }

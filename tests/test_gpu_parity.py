@@ -314,3 +314,21 @@ def test_other_phnn_shapes_vs_oracle(torch_cuda, shape):
         ref = m64.rollout(x0, U, cost, integ, 0.01, nthreads=8)
         c, gu, gx = eng.rollout_cost_grad(x0, U, cost, integ, 0.01, want_grad_x0=True)
         assert_rollout_close(npy(c), None, npy(gu), npy(gx), ref["cost"], None, ref["grad_u"], ref["grad_x0"])
+
+
+def test_default_matmul_mode_by_width(torch_cuda):
+    """128-wide models default to the f16x2 products, 64-wide ones to all-f32 (PHNN_MATMUL overrides either)."""
+    import os
+    from phnn_mpc_amd.engine import RolloutEngine
+    assert "PHNN_MATMUL" not in os.environ
+    assert RolloutEngine(ol.load_weights("phnn_cartpole")).matmul_mode == "f16x2"
+    assert RolloutEngine(ol.load_weights("phnn_pendulum")).matmul_mode == "f32"
+    os.environ["PHNN_MATMUL"] = "f16x2"
+    try:
+        eng = RolloutEngine(ol.load_weights("phnn_pendulum"))
+    finally:
+        os.environ.pop("PHNN_MATMUL", None)
+    assert eng.matmul_mode == "f16x2"
+    g = ol.load_golden("phnn_pendulum")
+    dx, H = eng.forward(g["fwd_x"], g["fwd_u"])
+    assert np.abs(npy(dx) - g["fwd_dx_f64"]).max() <= 2e-5 * np.abs(g["fwd_dx_f64"]).max()
