@@ -552,14 +552,21 @@ struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int SIZE = oB3 + 4;
 };
 
-template <int HID>
+template <int HID, int MM = MM_F32>
 struct LayH1 {  // in(<=4) -> HID -> out(<=16)  (R_net, G_net)
   static constexpr int T = HID / 16, LD = HID + 4, LR = HID + 8;
-  static constexpr int oV2 = 0;                 // [16][LD]
-  static constexpr int oV1f = oV2 + 16 * LD;    // [T][64]
+  static constexpr bool HF = MM == MM_F16X2;    // output layer as f16x2 products (h1_fwd / h1_bwd)
+  static constexpr int RS = HID + 16;           // f16 per row of the forward image (same stride as HfImg)
+  static constexpr int FPART = 16 * RS * 2;     // bytes per part of the forward image  [16 outputs][RS], k-slot order
+  static constexpr int BPART = HID * 16 * 2;    // bytes per part of the transposed image [HID units][16 outputs]
+  static constexpr int oV2 = 0;                 // f32: [16][LD];  f16x2: forward image (hi, lo) of Sr * V2 ...
+  static constexpr int oV2T = oV2 + 2 * FPART / 4;  // ... then the transposed image (hi, lo) of Sr * V2^T
+  static constexpr int V2F = HF ? (2 * FPART + 2 * BPART) / 4 : 16 * LD;
+  static constexpr int oV1f = oV2 + V2F;        // [T][64]
   static constexpr int oC1 = oV1f + T * 64;     // [HID]
   static constexpr int oC2 = oC1 + HID;         // [16]
-  static constexpr int oV1T = oC2 + 16;         // [4][LR]
+  static constexpr int oSc = oC2 + 16;          // [4] (1 / Sr, 0, 0, 0)
+  static constexpr int oV1T = oSc + 4;          // [4][LR]
   static constexpr int SIZE = oV1T + 4 * LR;
 };
 
@@ -705,35 +712,92 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   return MM == MM_F16X2 ? Hv * unscale : Hv;
 }
 
-// one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations
-template <int HID>
+// one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations.
+// MM_F16X2: the HID -> 16 output layer runs as 3 x T/2 v_mfma_f32_16x16x32_f16 (three independent chains) on the
+// hi/lo split of the hidden activations instead of 2T dependent-pair f32 MFMAs of 32 cycles each.
+template <int HID, int MM = MM_F32>
 DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, float (&out)[16]) {
-  using Y = LayH1<HID>;
+  using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(h, L + Y::oC1, ln);
   in_layer<T>(h, L + Y::oV1f, ln, sel4(x, ln.q));
   tanh_act<T>(h);
   Act<1> o;
-  o.v[0] = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
-  sq_fwd<1, T>(o, L + Y::oV2, ln, h);
+  if (Y::HF) {
+    Split2<T> sp;
+    split_act_h<T>(h, sp);
+    keep_lds_reads_local();
+    const char* base = reinterpret_cast<const char*>(L + Y::oV2) + ln.i * (Y::RS * 2) + ln.q * 16;
+    f32x4 o0 = splat4(0.f), o1 = splat4(0.f), o2 = splat4(0.f);
+#pragma unroll
+    for (int s = 0; s < T / 2; ++s) {
+      f16x8 ah = *reinterpret_cast<const f16x8*>(base + s * 64);
+      f16x8 al = *reinterpret_cast<const f16x8*>(base + Y::FPART + s * 64);
+      o0 = mfma_h(al, sp.h[s], o0);
+      o1 = mfma_h(ah, sp.l[s], o1);
+      o2 = mfma_h(ah, sp.h[s], o2);
+    }
+    const float inv = L[Y::oSc];
+    f32x4 c2 = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
+    o.v[0] = ((o0 + o1) + o2) * inv + c2;
+  } else {
+    o.v[0] = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
+    sq_fwd<1, T>(o, L + Y::oV2, ln, h);
+  }
   gather16(scr, ln, o.v[0], out);
 }
 
-// xbar = (d net / d x)^T obar, obar given as all 16 values in every lane
-template <int HID>
+// xbar = (d net / d x)^T obar, obar given as all 16 values in every lane.
+// MM_F16X2: obar is normalised per rollout by a power of two (the map is linear), split hi/lo and STACKED along the
+// K = 32 of one MFMA: k-slots 0..15 carry hi(obar), 16..31 lo(obar), against [V2^T hi | V2^T hi]; a second MFMA adds
+// V2^T lo x hi(obar).  Two 16-cycle MFMAs per tile of hidden units instead of four 32-cycle f32 ones.
+template <int HID, int MM = MM_F32>
 DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&obar)[16]) {
-  using Y = LayH1<HID>;
+  using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
-  Act<1> ob;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-    ob.v[0][r] = ln.q == 0 ? obar[r] : (ln.q == 1 ? obar[4 + r] : (ln.q == 2 ? obar[8 + r] : obar[12 + r]));
   Act<T> hb;
-  zero_act<T>(hb);
-  sq_bwd<T, 1>(hb, L + Y::oV2, ln, ob);
+  float unscale = 1.0f;
+  if (Y::HF) {
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mx = fmaxf(mx, __builtin_fabsf(obar[k]));
+    int e = 0;
+    (void)__builtin_frexpf(mx, &e);
+    e = (mx > 0.f && mx < 3.0e38f) ? e : 0;
+    const float sc = __builtin_ldexpf(1.0f, -e);
+    unscale = __builtin_ldexpf(1.0f, e) * L[Y::oSc];
+    const bool second = (ln.q & 1) != 0, lo_half = ln.q >= 2;
+    u32x4 B1, B2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f32x2 v = {(second ? obar[8 + 2 * p] : obar[2 * p]) * sc, (second ? obar[9 + 2 * p] : obar[2 * p + 1]) * sc};
+      f16x2 hb2 = __builtin_convertvector(v, f16x2);
+      f32x2 r = v - __builtin_convertvector(hb2, f32x2);
+      unsigned hbits = __builtin_bit_cast(unsigned, hb2), lbits = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+      B1[p] = lo_half ? lbits : hbits;
+      B2[p] = lo_half ? 0u : hbits;
+    }
+    const f16x8 b1 = __builtin_bit_cast(f16x8, B1), b2 = __builtin_bit_cast(f16x8, B2);
+    keep_lds_reads_local();
+    const char* base = reinterpret_cast<const char*>(L + Y::oV2T) + ln.i * 32 + (ln.q & 1) * 16;
+#pragma unroll
+    for (int nt = 0; nt < T; ++nt) {
+      f16x8 ah = *reinterpret_cast<const f16x8*>(base + nt * 512);
+      f16x8 al = *reinterpret_cast<const f16x8*>(base + Y::BPART + nt * 512);
+      hb.v[nt] = mfma_h(ah, b1, mfma_h(al, b2, splat4(0.f)));
+    }
+  } else {
+    Act<1> ob;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      ob.v[0][r] = ln.q == 0 ? obar[r] : (ln.q == 1 ? obar[4 + r] : (ln.q == 2 ? obar[8 + r] : obar[12 + r]));
+    zero_act<T>(hb);
+    sq_bwd<T, 1>(hb, L + Y::oV2, ln, ob);
+  }
 #pragma unroll
   for (int t = 0; t < T; ++t) hb.v[t] = hb.v[t] * (1.0f - h.v[t] * h.v[t]);
-  return to4_rep<T>(L + Y::oV1T, ln, hb);
+  f32x4 xb = to4_rep<T>(L + Y::oV1T, ln, hb);
+  return Y::HF ? xb * unscale : xb;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -746,8 +810,8 @@ struct PhnnModel {
   static constexpr int SCR = kScrFloats;  // per-wave LDS scratch (exchange of the 16 R_net / G_net outputs)
   static constexpr int oH = 0;
   static constexpr int oR = oH + LayH2<HID, MM>::SIZE;
-  static constexpr int oGn = oR + LayH1<HID>::SIZE;
-  static constexpr int oJ = oGn + (FIXG ? 0 : LayH1<HID>::SIZE);  // [16] J - J^T, row-major N x N
+  static constexpr int oGn = oR + LayH1<HID, MM>::SIZE;
+  static constexpr int oJ = oGn + (FIXG ? 0 : LayH1<HID, MM>::SIZE);  // [16] J - J^T, row-major N x N
   static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
   static constexpr int IMG = oG + 4;
 
@@ -767,7 +831,7 @@ struct PhnnModel {
     }
     Act<T> hR;
     float rf[16];
-    h1_fwd<HID>(L + oR, scr, ln, x, hR, rf);
+    h1_fwd<HID, MM>(L + oR, scr, ln, x, hR, rf);
     float G[N];
     if (FIXG) {
 #pragma unroll
@@ -775,7 +839,7 @@ struct PhnnModel {
     } else {
       Act<T> hG;
       float gf[16];
-      h1_fwd<HID>(L + oGn, scr, ln, x, hG, gf);
+      h1_fwd<HID, MM>(L + oGn, scr, ln, x, hG, gf);
 #pragma unroll
       for (int i = 0; i < N; ++i) G[i] = gf[i];
     }
@@ -829,7 +893,7 @@ struct PhnnModel {
     {
       Act<T> hR;
       float rf[16];
-      h1_fwd<HID>(L + oR, scr, ln, x, hR, rf);
+      h1_fwd<HID, MM>(L + oR, scr, ln, x, hR, rf);
 #pragma unroll
       for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -857,7 +921,7 @@ struct PhnnModel {
           float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
           rbar[i * N + j] = (sij + sji) * 0.5f;
         }
-      xb += h1_bwd<HID>(L + oR, ln, hR, rbar);
+      xb += h1_bwd<HID, MM>(L + oR, ln, hR, rbar);
     }
     ubar = 0.f;
     if (FIXG) {
@@ -866,7 +930,7 @@ struct PhnnModel {
     } else {
       Act<T> hG;
       float gf[16], gbar[16];
-      h1_fwd<HID>(L + oGn, scr, ln, x, hG, gf);
+      h1_fwd<HID, MM>(L + oGn, scr, ln, x, hG, gf);
 #pragma unroll
       for (int k = 0; k < 16; ++k) gbar[k] = 0.f;
 #pragma unroll
@@ -874,7 +938,7 @@ struct PhnnModel {
         ubar = __builtin_fmaf(gf[i], lam[i], ubar);
         gbar[i] = lam[i] * u;
       }
-      xb += h1_bwd<HID>(L + oGn, ln, hG, gbar);
+      xb += h1_bwd<HID, MM>(L + oGn, ln, hG, gbar);
     }
     // v = A^T lam, A = Jeff - S S^T
     f32x4 v = splat4(0.f);

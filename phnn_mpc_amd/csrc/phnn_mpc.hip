@@ -375,14 +375,39 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   return p;
 }
 
-template <int HID>
+template <int HID, int MM>
 const float* pack_h1(float* dst, const float* p, int nin, int nout) {  // R_net / G_net
-  using Y = LayH1<HID>;
+  using Y = LayH1<HID, MM>;
   const float* V1 = p; p += (size_t)HID * nin;
   const float* c1 = p; p += HID;
   const float* V2 = p; p += (size_t)nout * HID;
   const float* c2 = p; p += nout;
-  pack_rows(dst + Y::oV2, V2, nout, HID, Y::LD);
+  if (Y::HF) {
+    // Sr * V2 as f16 hi/lo, twice: rows = outputs with the hidden units in k-slot order (forward), and rows =
+    // hidden units with the 16 outputs in natural order (transposed product); Sr = 2^k, max|V2| Sr in [0.5, 1)
+    float mx = 0.f;
+    for (int k = 0; k < nout * HID; ++k) mx = std::fmax(mx, std::fabs(V2[k]));
+    int e = 0;
+    if (mx > 0.f) (void)std::frexp(mx, &e);
+    const float Sr = std::ldexp(1.0f, -e);
+    _Float16* fw = reinterpret_cast<_Float16*>(dst + Y::oV2);
+    _Float16* bw = reinterpret_cast<_Float16*>(dst + Y::oV2T);
+    for (int o = 0; o < nout; ++o)
+      for (int pos = 0; pos < HID; ++pos) {
+        int s = pos / 32, w = pos % 32, q = w / 8, j = w % 8;
+        int u = 32 * s + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
+        float x = V2[(size_t)o * HID + u] * Sr;
+        _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+        fw[(size_t)o * Y::RS + pos] = h;
+        fw[(size_t)Y::FPART / 2 + (size_t)o * Y::RS + pos] = l;
+        bw[(size_t)u * 16 + o] = h;
+        bw[(size_t)Y::BPART / 2 + (size_t)u * 16 + o] = l;
+      }
+    dst[Y::oSc] = 1.0f / Sr;
+  } else {
+    pack_rows(dst + Y::oV2, V2, nout, HID, Y::LD);
+    dst[Y::oSc] = 1.0f;
+  }
   pack_in_frag<HID>(dst + Y::oV1f, V1, nin);
   memcpy(dst + Y::oC1, c1, sizeof(float) * HID);
   memcpy(dst + Y::oC2, c2, sizeof(float) * nout);
@@ -397,9 +422,9 @@ void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
   const float* J = p; p += N * N;
   const float* G = nullptr;
   if (d->fixed_G) { G = p; p += N; }
-  p = pack_h1<HID>(img.data() + M::oR, p, N, N * N);
+  p = pack_h1<HID, M::MM>(img.data() + M::oR, p, N, N * N);
   p = pack_h2<HID, M::MM>(img.data() + M::oH, p, N);
-  if (!d->fixed_G) p = pack_h1<HID>(img.data() + M::oGn, p, N, N);
+  if (!d->fixed_G) p = pack_h1<HID, M::MM>(img.data() + M::oGn, p, N, N);
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) img[M::oJ + i * N + j] = J[i * N + j] - J[j * N + i];  // src/pHNN.py:83, no 1/2
   if (G)
