@@ -40,6 +40,9 @@ DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x
 
 DEV f32x4 splat4(float s) { return f32x4{s, s, s, s}; }
 
+// 1 - a^2 (derivative of tanh at its output) as one fused op per element instead of mul + sub
+DEV f32x4 dtanh(f32x4 a) { return __builtin_elementwise_fma(-a, a, f32x4{1.0f, 1.0f, 1.0f, 1.0f}); }
+
 DEV float sel4(f32x4 v, int q) { return q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : v[3])); }
 
 // tanh in float32.  f32 MFMA and VALU share the SIMD's vector ALUs on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0
@@ -358,6 +361,16 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 DEV f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// x - (float)h for a packed pair, one v_fma_mix_f32 each (f16 operand read straight from the packed register:
+// replaces v_cvt_f32_f16 + v_sub_f32; the compiler does not form it from the plain expression)
+DEV f32x2 residual_h(f16x2 h, f32x2 x) {
+  unsigned hb = __builtin_bit_cast(unsigned, h);
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hb), "v"(x[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hb), "v"(x[1]));
+  return r;
+}
+
 template <int T>
 struct Split2 {
   f16x8 h[T / 2], l[T / 2];
@@ -372,7 +385,7 @@ DEV void split_act_h(const Act<T>& a, Split2<T>& o) {
     for (int p = 0; p < 4; ++p) {
       f32x2 x = {a.v[2 * s + (p >> 1)][2 * (p & 1)], a.v[2 * s + (p >> 1)][2 * (p & 1) + 1]};
       f16x2 hb = __builtin_convertvector(x, f16x2);
-      f32x2 r = x - __builtin_convertvector(hb, f32x2);
+      f32x2 r = residual_h(hb, x);
       H[p] = __builtin_bit_cast(unsigned, hb);
       Lo[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     }
@@ -617,7 +630,7 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
       for (int r = 0; r < 4; ++r) s = __builtin_fmaf(w3[r], tp.a2.v[t][r], s);
     }
     f32x4 w3b = *reinterpret_cast<const f32x4*>(L + Y::oW3B + 16 * t + 4 * ln.q);
-    g.v[t] = w3b * (1.0f - tp.a2.v[t] * tp.a2.v[t]);
+    g.v[t] = w3b * dtanh(tp.a2.v[t]);
   }
   if (WANT_H) Hval = reduce_q(s) + L[Y::oB3];
   zero_act<T>(tp.q1);
@@ -633,7 +646,7 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
     sq_bwd<T, T>(tp.q1, L + Y::oW2, ln, g);
   }
 #pragma unroll
-  for (int t = 0; t < T; ++t) g.v[t] = tp.q1.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
+  for (int t = 0; t < T; ++t) g.v[t] = tp.q1.v[t] * dtanh(tp.a1.v[t]);
   return to4_rep<T>(L + Y::oW1T, ln, g);
 }
 
@@ -666,10 +679,12 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   zero_act<T>(ad1);
   in_layer<T>(ad1, L + Y::oW1f, ln, sel4(v, ln.q));
 #pragma unroll
-  for (int t = 0; t < T; ++t) ad1.v[t] = (1.0f - tp.a1.v[t] * tp.a1.v[t]) * ad1.v[t];
-  // second term of gdot1 = qdot1*(1-a1^2) + q1*(-2 a1 adot1): fold it now, adot1 dies after the product
+  for (int t = 0; t < T; ++t) ad1.v[t] = dtanh(tp.a1.v[t]) * ad1.v[t];
+  // gdot1 = qdot1*(1-a1^2) + q1*(-2 a1 adot1) and gdot2 = w3 (-2 a2 (1-a2^2) zdot2): both carry a factor -2, so the
+  // rest of this function works with -1/2 of the true quantities and the factor is restored on the final 4-vector.
+  // Second term of gdot1 folded now, adot1 dies after the product.
 #pragma unroll
-  for (int t = 0; t < T; ++t) tp.q1.v[t] = tp.q1.v[t] * (-2.0f * tp.a1.v[t] * ad1.v[t]);
+  for (int t = 0; t < T; ++t) tp.q1.v[t] = tp.q1.v[t] * (tp.a1.v[t] * ad1.v[t]);
   zero_act<T>(w);
   if (MM == MM_BF16X3) {
     Split3<T> sp;
@@ -687,8 +702,8 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   for (int t = 0; t < T; ++t) {
     f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3S + 16 * t + 4 * ln.q);  // w3 / S: w holds S * zdot2
     f32x4 a2 = tp.a2.v[t];
-    f32x4 ad2 = (1.0f - a2 * a2) * w.v[t];
-    w.v[t] = w3 * (-2.0f * a2 * ad2);  // gdot2
+    f32x4 ad2 = dtanh(a2) * w.v[t];
+    w.v[t] = w3 * (a2 * ad2);  // -gdot2 / 2
   }
   Act<T> qd;
   zero_act<T>(qd);
@@ -705,11 +720,10 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   }
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    f32x4 a1 = tp.a1.v[t];
-    qd.v[t] = qd.v[t] * (1.0f - a1 * a1) + tp.q1.v[t];
+    qd.v[t] = __builtin_elementwise_fma(qd.v[t], dtanh(tp.a1.v[t]), tp.q1.v[t]);
   }
   f32x4 Hv = to4_rep<T>(L + Y::oW1T, ln, qd);
-  return MM == MM_F16X2 ? Hv * unscale : Hv;
+  return Hv * (-2.0f * unscale);
 }
 
 // one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations.
@@ -772,7 +786,7 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
     for (int p = 0; p < 4; ++p) {
       f32x2 v = {(second ? obar[8 + 2 * p] : obar[2 * p]) * sc, (second ? obar[9 + 2 * p] : obar[2 * p + 1]) * sc};
       f16x2 hb2 = __builtin_convertvector(v, f16x2);
-      f32x2 r = v - __builtin_convertvector(hb2, f32x2);
+      f32x2 r = residual_h(hb2, v);
       unsigned hbits = __builtin_bit_cast(unsigned, hb2), lbits = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
       B1[p] = lo_half ? lbits : hbits;
       B2[p] = lo_half ? 0u : hbits;
@@ -795,7 +809,7 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
     sq_bwd<T, 1>(hb, L + Y::oV2, ln, ob);
   }
 #pragma unroll
-  for (int t = 0; t < T; ++t) hb.v[t] = hb.v[t] * (1.0f - h.v[t] * h.v[t]);
+  for (int t = 0; t < T; ++t) hb.v[t] = hb.v[t] * dtanh(h.v[t]);
   f32x4 xb = to4_rep<T>(L + Y::oV1T, ln, hb);
   return Y::HF ? xb * unscale : xb;
 }
@@ -1155,13 +1169,13 @@ struct OdeModel {
     zero_act<T>(d);
     in_layer<T>(d, L + oW4f, ln, sel4(lam, ln.q));
 #pragma unroll
-    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * (1.0f - tp.a3.v[t] * tp.a3.v[t]);
+    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * dtanh(tp.a3.v[t]);
     hidden_T(L, ln, oW3, d, e);
 #pragma unroll
-    for (int t = 0; t < T; ++t) e.v[t] = e.v[t] * (1.0f - tp.a2.v[t] * tp.a2.v[t]);
+    for (int t = 0; t < T; ++t) e.v[t] = e.v[t] * dtanh(tp.a2.v[t]);
     hidden_T(L, ln, oW2, e, d);
 #pragma unroll
-    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * (1.0f - tp.a1.v[t] * tp.a1.v[t]);
+    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * dtanh(tp.a1.v[t]);
     f32x4 inb = to4_rep<T>(L + oW1T, ln, d);
     if (MM == MM_F16X2) inb = inb * unscale;
     if (WIDE) {
