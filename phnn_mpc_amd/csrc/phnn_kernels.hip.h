@@ -119,6 +119,22 @@ DEV void tanh_act(Act<T>& a) {
     for (int r = 0; r < 4; ++r) a.v[t][r] = tanh_dev<ACCURATE>(a.v[t][r]);
 }
 
+// H_net / R_net / G_net of the 128-wide models: 2 log2(e) is multiplied into the weights and bias that produce the
+// pre-activation when the image is packed (kPreScaled), so tanh is exp2, add, rcp, fma -- one multiply less per value.
+template <int T>
+constexpr bool kPreScaled = T > 4;
+
+template <int T>
+DEV void tanh_act_pre(Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (kPreScaled<T>) a.v[t][r] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a.v[t][r]) + 1.0f), 1.0f);
+      else a.v[t][r] = tanh_dev<true>(a.v[t][r]);
+    }
+}
+
 // o[t] = vec[16t + 4q .. +3]  (vector in natural unit order in LDS: bias, output weights)
 template <int T>
 DEV void load_vec(Act<T>& o, const float* vec, Lane ln) {
@@ -561,7 +577,7 @@ struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int oW3B = oW3 + HID;         // [HID]   w3 * Sb (g2 = w3 (1 - a2^2), fed to the transposed product)
   static constexpr int oW3S = oW3B + HID;        // [HID]   w3 * Sb / S (used by the Hessian-vector product)
   static constexpr int oW1T = oW3S + HID;        // [4][LR] rows c = W1[:,c] / (S Sb)
-  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 0, 0)
+  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 1 / k1, 0), k1 = factor folded into W1, b1
   static constexpr int SIZE = oB3 + 4;
 };
 
@@ -597,7 +613,7 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
   constexpr int T = Y::T;
   load_vec<T>(tp.a1, L + Y::oB1, ln);
   in_layer<T>(tp.a1, L + Y::oW1f, ln, sel4(z, ln.q));
-  tanh_act<T>(tp.a1);
+  tanh_act_pre<T>(tp.a1);
   load_vec<T>(tp.a2, L + Y::oB2, ln);
   if (MM == MM_BF16X3) {
     Split3<T> sp;
@@ -610,12 +626,19 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
   } else {
     sq_fwd<T, T>(tp.a2, L + Y::oW2, ln, tp.a1);
   }
-  if (MM == MM_F16X2) {  // the accumulator holds S * z2: the scale rides in the exp2 constant
+  if (MM == MM_F16X2 || kPreScaled<T>) {
+    // the accumulator holds S * z2; c = 2 log2(e) / S.  128-wide: 2 log2(e) is folded into the image and the f16
+    // image needs no further power of two for ordinary weights (max |2.89 w| in [0.5, 1024)), so c == 1 and the
+    // multiply disappears; the branch is uniform.
     const float c = L[Y::oB3 + 1];
+    if (kPreScaled<T> && c == 1.0f) {
+      tanh_act_pre<T>(tp.a2);
+    } else {
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tp.a2.v[t][r] = tanh_scaled(tp.a2.v[t][r], c);
+        for (int r = 0; r < 4; ++r) tp.a2.v[t][r] = tanh_scaled(tp.a2.v[t][r], c);
+    }
   } else {
     tanh_act<T>(tp.a2);
   }
@@ -657,7 +680,7 @@ DEV void hnet_layer1(const float* L, Lane ln, f32x4 z, Act<HID / 16>& a1) {
   using Y = LayH2<HID, MM>;
   load_vec<Y::T>(a1, L + Y::oB1, ln);
   in_layer<Y::T>(a1, L + Y::oW1f, ln, sel4(z, ln.q));
-  tanh_act<Y::T>(a1);
+  tanh_act_pre<Y::T>(a1);
 }
 
 // Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
@@ -723,7 +746,7 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
     qd.v[t] = __builtin_elementwise_fma(qd.v[t], dtanh(tp.a1.v[t]), tp.q1.v[t]);
   }
   f32x4 Hv = to4_rep<T>(L + Y::oW1T, ln, qd);
-  return Hv * (-2.0f * unscale);
+  return Hv * (-2.0f * unscale * L[Y::oB3 + 2]);  // oB3[2]: 1 / (scale folded into W1)
 }
 
 // one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations.
@@ -735,7 +758,7 @@ DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, 
   constexpr int T = Y::T;
   load_vec<T>(h, L + Y::oC1, ln);
   in_layer<T>(h, L + Y::oV1f, ln, sel4(x, ln.q));
-  tanh_act<T>(h);
+  tanh_act_pre<T>(h);
   Act<1> o;
   if (Y::HF) {
     Split2<T> sp;

@@ -306,14 +306,16 @@ void pack_bf16x3(float* dstf, const float* W) {
     }
 }
 
-// W -> two f16 parts of S * W in the same permuted layout; returns S = 2^k with max|W| S in [0.5, 1)
+// W -> two f16 parts of S * W in the same permuted layout; returns the power of two S.  S = 1 while max|W| lies in
+// [0.5, 1024): the hi/lo pair then resolves 2^-25 absolute, i.e. <= 2^-24 of the largest weight, and f16's range is
+// far away.  Smaller matrices are scaled up into [0.5, 1) (keeps that relative resolution), larger ones down.
 template <int HID>
 float pack_f16x2(float* dstf, const float* W) {
   using I = HfImg<HID>;
   float mx = 0.f;
   for (int k = 0; k < HID * HID; ++k) mx = std::fmax(mx, std::fabs(W[k]));
   int e = 0;
-  if (mx > 0.f) (void)std::frexp(mx, &e);
+  if (mx > 0.f && (mx < 0.5f || mx >= 1024.0f)) (void)std::frexp(mx, &e);
   const float S = std::ldexp(1.0f, -e);
   _Float16* dst = reinterpret_cast<_Float16*>(dstf);
   for (int r = 0; r < HID; ++r)
@@ -339,12 +341,19 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   const float* b2 = p; p += HID;
   const float* W3 = p; p += HID;
   const float* b3 = p; p += 1;
-  float S = 1.0f;  // power-of-two scale carried by the W2 image (f16x2 only)
-  if (MM == MM_BF16X3) pack_bf16x3<HID>(dst + Y::oW2, W2);
-  else if (MM == MM_F16X2) S = pack_f16x2<HID>(dst + Y::oW2, W2);
-  else pack_rows(dst + Y::oW2, W2, HID, HID, Y::LD);
-  pack_in_frag<HID>(dst + Y::oW1f, W1, nin);
-  memcpy(dst + Y::oB1, b1, sizeof(float) * HID);
+  // 128-wide: tanh's 2 log2(e) is folded into the weights and biases in front of each tanh (kPreScaled in the
+  // kernels); every later use of those pre-activations' scale goes through S and k1 below.
+  const float k1 = kPreScaled<HID / 16> ? 2.8853900817779268f : 1.0f;
+  std::vector<float> W1s((size_t)HID * nin), W2s((size_t)HID * HID);
+  for (size_t k = 0; k < W1s.size(); ++k) W1s[k] = W1[k] * k1;
+  for (size_t k = 0; k < W2s.size(); ++k) W2s[k] = W2[k] * k1;
+  float S = 1.0f;  // scale carried by the second pre-activation: k1 x (f16x2: the image's power of two)
+  if (MM == MM_BF16X3) pack_bf16x3<HID>(dst + Y::oW2, W2s.data());
+  else if (MM == MM_F16X2) S = pack_f16x2<HID>(dst + Y::oW2, W2s.data());
+  else pack_rows(dst + Y::oW2, W2s.data(), HID, HID, Y::LD);
+  S *= k1;
+  pack_in_frag<HID>(dst + Y::oW1f, W1s.data(), nin);
+  for (int k = 0; k < HID; ++k) dst[Y::oB1 + k] = b1[k] * k1;
   memcpy(dst + Y::oW3, W3, sizeof(float) * HID);
   pack_cols_as_rows(dst + Y::oW1T, W1, HID, nin, Y::LR);
   // Sb: power of two (<= 1) that keeps the backward-type MFMA inputs g2 = w3 (1-a2^2) and
@@ -372,6 +381,7 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   for (int k = 0; k < 4 * Y::LR; ++k) dst[Y::oW1T + k] /= (S * Sb);
   dst[Y::oB3] = b3[0];
   dst[Y::oB3 + 1] = 2.8853900817779268f / S;
+  dst[Y::oB3 + 2] = 1.0f / k1;
   return p;
 }
 
@@ -408,8 +418,11 @@ const float* pack_h1(float* dst, const float* p, int nin, int nout) {  // R_net 
     pack_rows(dst + Y::oV2, V2, nout, HID, Y::LD);
     dst[Y::oSc] = 1.0f;
   }
-  pack_in_frag<HID>(dst + Y::oV1f, V1, nin);
-  memcpy(dst + Y::oC1, c1, sizeof(float) * HID);
+  const float k1 = kPreScaled<HID / 16> ? 2.8853900817779268f : 1.0f;  // folded tanh constant (see pack_h2)
+  std::vector<float> V1s((size_t)HID * nin);
+  for (size_t k = 0; k < V1s.size(); ++k) V1s[k] = V1[k] * k1;
+  pack_in_frag<HID>(dst + Y::oV1f, V1s.data(), nin);
+  for (int k = 0; k < HID; ++k) dst[Y::oC1 + k] = c1[k] * k1;
   memcpy(dst + Y::oC2, c2, sizeof(float) * nout);
   pack_cols_as_rows(dst + Y::oV1T, V1, HID, nin, Y::LR);
   return p;
