@@ -9,6 +9,23 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
+// bf16 MFMA 16x16x32 stream that leaves the vector issue port alone for a while after each MFMA:
+// Y = 1: s_nop 0, 2: s_nop 1, 3: two scalar moves
+template <int Y>
+__device__ float mfma_yield(int n, float seed) {
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(seed + j); b[j] = (__bf16)(0.5f + j); }
+  f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+#define YIELD() do { if (Y == 1) asm volatile("s_nop 0"); else if (Y == 2) asm volatile("s_nop 1"); else asm volatile("s_mov_b32 s20, 0\n s_mov_b32 s21, 0" ::: "s20", "s21"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  for (int k = 0; k < n; ++k) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0); YIELD();
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0); YIELD();
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0); YIELD();
+    c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0); YIELD();
+  }
+  return c0[0] + c1[1] + c2[2] + c3[3];
+}
+
 __device__ float run_role(int role, int n, float seed) {
   float acc = seed;
   if (role == 1) {
@@ -40,6 +57,9 @@ __device__ float run_role(int role, int n, float seed) {
       x6 = __builtin_fmaf(x6, 0.999f, 0.001f); x7 = __builtin_fmaf(x7, 0.999f, 0.001f);
     }
     acc = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+  } else if (role == 5) { acc = mfma_yield<1>(n, seed);
+  } else if (role == 6) { acc = mfma_yield<2>(n, seed);
+  } else if (role == 7) { acc = mfma_yield<3>(n, seed);
   } else if (role == 4) {
     bf16x8 a, b;
     for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(seed + j); b[j] = (__bf16)(0.5f + j); }
@@ -73,10 +93,11 @@ int main() {
     return (double)T;
   };
   const int N = 4000;
-  const char* names[5] = {"-", "bf16 16x16x32", "f32 16x16x4", "VALU fma", "bf16 32x32x16"};
+  const char* names[8] = {"-", "bf16 16x16x32", "f32 16x16x4", "VALU fma", "bf16 32x32x16", "bf16+s_nop0", "bf16+s_nop1", "bf16+2 s_mov"};
   struct { int a, na, b, nb; } cases[] = {
       {1, N, 0, 0}, {3, 0, 3, 4 * N}, {1, N, 3, 4 * N}, {1, N, 1, N},
-      {2, N, 0, 0}, {2, N, 3, 4 * N}, {4, N, 0, 0}, {4, N, 3, 4 * N}, {4, N, 4, N}, {3, 4 * N, 3, 4 * N}};
+      {2, N, 0, 0}, {2, N, 3, 4 * N}, {4, N, 0, 0}, {4, N, 3, 4 * N}, {4, N, 4, N}, {3, 4 * N, 3, 4 * N},
+      {5, N, 0, 0}, {5, N, 3, 4 * N}, {6, N, 0, 0}, {6, N, 3, 4 * N}, {7, N, 0, 0}, {7, N, 3, 4 * N}, {1, N, 3, 2 * N}, {6, N, 3, 2 * N}};
   for (auto c : cases) {
     double t = run(c.a, c.na, c.b, c.nb);
     printf("waves0-3: %-14s x%-6d | waves4-7: %-14s x%-6d -> %10.0f ticks\n", names[c.a], c.a ? (c.a == 3 ? c.na * 8 : c.na * (c.a == 4 ? 2 : 4)) : 0,
