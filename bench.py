@@ -117,13 +117,16 @@ def main():
         c = ws_cost
         if ev is not None:
             ev[1].record()
+        work = None
+        if world > 1 and backend == "nccl":  # costs are final after K1: the all-gather runs on RCCL's stream under K2
+            work = dist.all_gather_into_tensor(gathered, c, async_op=True)
         eng.lib.phnn_rollout_grad(eng.h, eng._p(x0), eng._p(U), B, H, cost_ref, integ, float(dt), eng._p(ws_traj),
                                   eng._p(ws_stash), eng._p(ws_gu), None, eng._stream())
         if ev is not None:
             ev[2].record()
         if world > 1:
-            if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, c)
+            if work is not None:
+                work.wait()  # stream-level wait: the next step's K1 must not overwrite c before the gather has read it
             else:  # rehearsal backend: collectives on host copies
                 parts = [torch.empty(B, dtype=torch.float32) for _ in range(world)]
                 dist.all_gather(parts, c.cpu())

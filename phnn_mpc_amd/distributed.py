@@ -2,7 +2,8 @@
 
 The path partitions into independent units (rollout b depends only on x0[b], u[b] and the weights), so ranks
 never exchange states, controls or gradients.  The single collective is one all-gather of cost[B/G] float32 per
-pass (RCCL over xGMI when the backend is "nccl"; 512 KB per rank at B = 2^20 over 8 GPUs, latency-bound).
+pass (RCCL over xGMI when the backend is "nccl"; 512 KB per rank at B = 2^20 over 8 GPUs, latency-bound); it is
+started as soon as K1 is enqueued and runs on RCCL's stream underneath K2.
 One process per GPU, launched with torch.distributed.run; the reference has no counterpart (no distributed code).
 """
 import torch
@@ -36,6 +37,34 @@ def all_gather_costs(local_cost, B, group=None):
     return torch.cat([buf[r * mx: r * mx + counts[r]] for r in range(world)])
 
 
+class _PendingGather:
+    """An all-gather of costs in flight (async_op): result() waits for it and returns the (B,) costs in batch order."""
+
+    def __init__(self, work, buf, counts, mx):
+        self.work, self.buf, self.counts, self.mx = work, buf, counts, mx
+
+    def result(self):
+        self.work.wait()  # the caller's stream waits for the collective; the host does not block on the GPU
+        if self.mx is None:
+            return self.buf
+        return torch.cat([self.buf[r * self.mx: r * self.mx + n] for r, n in enumerate(self.counts)])
+
+
+def all_gather_costs_async(local_cost, B, group=None):
+    """Start the all-gather of all_gather_costs and return a handle; the collective runs on the backend's own stream
+    (RCCL) while the caller keeps enqueueing work -- K2 -- on its stream."""
+    world = dist.get_world_size(group)
+    counts = [hi - lo for lo, hi in (shard_bounds(B, world, r) for r in range(world))]
+    if len(set(counts)) == 1:
+        out = torch.empty(B, dtype=local_cost.dtype, device=local_cost.device)
+        return _PendingGather(dist.all_gather_into_tensor(out, local_cost.contiguous(), group=group, async_op=True), out, counts, None)
+    mx = max(counts)
+    padded = torch.zeros(mx, dtype=local_cost.dtype, device=local_cost.device)
+    padded[: local_cost.numel()] = local_cost
+    buf = torch.empty(world * mx, dtype=local_cost.dtype, device=local_cost.device)
+    return _PendingGather(dist.all_gather_into_tensor(buf, padded, group=group, async_op=True), buf, counts, mx)
+
+
 class ShardedRollout:
     """engine: this rank's rollout engine (RolloutEngine bound to the rank's GPU).
 
@@ -60,7 +89,13 @@ class ShardedRollout:
             B_total = x0.shape[0]
             lo, hi = shard_bounds(B_total, self.world, self.rank)
             x0l, ul = x0[lo:hi], u[lo:hi]
-        c, g = self.engine.rollout_cost_grad(x0l, ul, cost, integrator, dt, workspace=workspace)
-        if self.world > 1:
-            c = all_gather_costs(c, B_total, self.group)
+        pending = []
+
+        def start_gather(local_cost):  # called between K1 and K2: the costs are final, the gather overlaps the adjoint
+            if self.world > 1:
+                pending.append(all_gather_costs_async(local_cost, B_total, self.group))
+
+        c, g = self.engine.rollout_cost_grad(x0l, ul, cost, integrator, dt, workspace=workspace, after_forward=start_gather)
+        if pending:
+            c = pending[0].result()
         return c, g, (lo, hi)

@@ -132,9 +132,11 @@ class RolloutEngine:
     def workspace_bytes(self, B, H, integrator="euler"):
         return int(self.lib.phnn_workspace_bytes(self.h, int(B), int(H), self._integ(integrator)))
 
-    def rollout_cost_grad(self, x0, u, cost, integrator="euler", dt=0.02, want_grad_x0=False, workspace=None):
+    def rollout_cost_grad(self, x0, u, cost, integrator="euler", dt=0.02, want_grad_x0=False, workspace=None,
+                          after_forward=None):
         """K1 + K2.  -> (cost (B), grad_u (B,H,m)[, grad_x0 (B,n)]).  `workspace`: optional dict reused across
-        calls to avoid re-allocating the trajectory / outputs."""
+        calls to avoid re-allocating the trajectory / outputs.  `after_forward(cost)` is called once K1 is enqueued
+        and before K2 is: the costs are final then, so a collective on them overlaps the adjoint kernel."""
         x0 = self._t(x0, (-1, self.n))
         B = x0.shape[0]
         u, H = self._controls(u, B)
@@ -155,6 +157,8 @@ class RolloutEngine:
         rc = self.lib.phnn_rollout_fwd(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), integ, float(dt),
                                        self._p(ws["cost"]), self._p(ws["traj"]), stash, st)
         _check(self.lib, self.h, rc)
+        if after_forward is not None:
+            after_forward(ws["cost"])
         rc = self.lib.phnn_rollout_grad(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), integ, float(dt),
                                         self._p(ws["traj"]), stash, self._p(ws["grad_u"]),
                                         self._p(ws["grad_x0"]) if want_grad_x0 else None, st)

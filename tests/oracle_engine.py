@@ -32,9 +32,12 @@ class OracleEngine:
         c, t = self._out(r["cost"]), self._out(r["traj"])
         return (c, t) if want_traj else c
 
-    def rollout_cost_grad(self, x0, u, cost, integrator="euler", dt=0.02, want_grad_x0=False, workspace=None):
+    def rollout_cost_grad(self, x0, u, cost, integrator="euler", dt=0.02, want_grad_x0=False, workspace=None,
+                          after_forward=None):
         r = self.m_.rollout(np.asarray(x0), np.asarray(u), cost, integrator, dt, grad=True, traj=False)
         out = (self._out(r["cost"]), self._out(r["grad_u"]))
+        if after_forward is not None:
+            after_forward(out[0])
         return out + (self._out(r["grad_x0"]),) if want_grad_x0 else out
 
     def adam_step(self, u, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, cost=None,
