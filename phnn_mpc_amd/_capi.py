@@ -110,6 +110,10 @@ def load_library():
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C phnn_mpc_amd/csrc`). "
             "There is no CPU fallback for the rollout engine.")
+    # torch first: it brings its own HIP runtime (same soname as the system one the library is linked against);
+    # the runtime that is loaded first serves both, and only torch's matches the rest of torch's ROCm libraries.
+    # Loading this library before torch leaves the process with a mixed set and no visible device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, f32p, i64, i32 = C.c_void_p, C.c_void_p, C.c_int64, C.c_int32
     lib.phnn_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(vp)]
