@@ -7,11 +7,13 @@ Reference behaviour kept:
   - every call cold-starts from zeros, runs max_iterations Adam steps and returns clamp(u_0) of the LAST iterate
     as a numpy array of shape (1,).
 """
+import os
+
 import numpy as np
 import torch
 
 from . import _capi
-from .solver import shooting_solve
+from .solver import solver_for
 
 
 class MPCController:
@@ -32,8 +34,15 @@ class MPCController:
         self.x_max = torch.tensor(x_max, dtype=torch.float32) if x_max is not None else None
         self.optimizer_type, self.lr, self.max_iterations = optimizer_type, lr, max_iterations
         self.integrator = "euler"  # src/mpc_controller.py:137-138
+        # True (or PHNN_GRAPH=1): replay the whole solve as one HIP graph instead of 3 x iterations launches
+        self.use_graph = os.environ.get("PHNN_GRAPH", "0") == "1"
+        self._graphed = None
 
     # ------------------------------------------------------------------ kernel parameters
+    def _solver(self, eng):
+        self._graphed = solver_for(eng, self.use_graph, self._graphed)
+        return self._graphed
+
     def _cost(self):
         return _capi.make_cost(self.state_dim, 1, self.Q.numpy(), float(self.R), self.target_state.numpy(),
                                self.u_min, self.u_max,
@@ -116,8 +125,8 @@ class MPCController:
         eng = self.engine
         x0 = torch.as_tensor(states, dtype=torch.float32).reshape(-1, self.state_dim).to(eng.device)
         u0 = torch.zeros(x0.shape[0], self.horizon, 1, dtype=torch.float32, device=eng.device)
-        return shooting_solve(eng, x0, u0, self._cost(), self.integrator, self.dt, self.lr, self.max_iterations,
-                              track_best=False, u_min=self.u_min, u_max=self.u_max, record_costs=record_costs)
+        return self._solver(eng)(eng, x0, u0, self._cost(), self.integrator, self.dt, self.lr, self.max_iterations,
+                                 track_best=False, u_min=self.u_min, u_max=self.u_max, record_costs=record_costs)
 
     def compute_control_batch(self, states):
         """states (B,n) -> np.ndarray (B,1): first control of each plant's optimised sequence."""

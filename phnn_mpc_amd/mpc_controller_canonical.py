@@ -6,13 +6,14 @@ clamped one (cost measured before the Adam step of the same iteration, strict '<
 208-214); control() warm-starts by shifting the previous sequence by one and zero-filling the tail (:252-255) and
 returns (u (m,), info{'u_sequence','solve_time','optimization'{'costs','final_cost','num_steps'}}).
 """
+import os
 import time
 
 import numpy as np
 import torch
 
 from . import _capi
-from .solver import shooting_solve
+from .solver import solver_for
 
 
 class MPCControllerCanonical:
@@ -34,6 +35,13 @@ class MPCControllerCanonical:
         self.x_target = torch.tensor(x_target, dtype=torch.float32)
         self.u_min, self.u_max = u_min, u_max
         self.integrator = "euler"
+        # True (or PHNN_GRAPH=1): replay the whole solve as one HIP graph instead of 3 x iterations launches
+        self.use_graph = os.environ.get("PHNN_GRAPH", "0") == "1"
+        self._graphed = None
+
+    def _solver(self, eng):
+        self._graphed = solver_for(eng, self.use_graph, self._graphed)
+        return self._graphed
 
     def _cost(self, clamp=True):
         c = _capi.make_cost(self.state_dim, self.input_dim, self.Q.numpy(), self.R.numpy(), self.x_target.numpy(),
@@ -99,9 +107,9 @@ class MPCControllerCanonical:
             u0 = torch.zeros(B, self.horizon, self.input_dim, dtype=torch.float32, device=eng.device)
         else:
             u0 = torch.as_tensor(u_init, dtype=torch.float32).reshape(B, self.horizon, self.input_dim).to(eng.device)
-        return shooting_solve(eng, x0, u0, self._cost(), self.integrator, self.dt, self.learning_rate,
-                              self.optimizer_steps, track_best=True, u_min=self.u_min, u_max=self.u_max,
-                              record_costs=record_costs)
+        return self._solver(eng)(eng, x0, u0, self._cost(), self.integrator, self.dt, self.learning_rate,
+                                 self.optimizer_steps, track_best=True, u_min=self.u_min, u_max=self.u_max,
+                                 record_costs=record_costs)
 
     def control_batch(self, x_current, u_prev=None):
         """x_current (B,n), u_prev (B,H,m) or None -> (u (B,m), u_sequence (B,H,m), best_cost (B)) numpy arrays."""

@@ -166,6 +166,42 @@ def test_controllers_on_gpu_match_reference(torch, ctl):
         assert np.array_equal(u1, ub[b]) and np.array_equal(info["u_sequence"], seq[b])
 
 
+def test_graphed_solve_is_bit_identical(torch, ctl):
+    """use_graph: the whole solve replayed as one HIP graph == the eager launch sequence, bit for bit, also when the
+    graph is replayed with new inputs (closed loop) and re-captured for another batch size."""
+    import time
+    from phnn_mpc_amd.models import pHNN, pHNN_Canonical
+    from phnn_mpc_amd.mpc_controller import create_mpc_from_config
+    from phnn_mpc_amd.mpc_controller_canonical import create_mpc_controller
+    cfg = yaml.safe_load(open(CFG))
+    c = create_mpc_from_config(_load(pHNN, CFG, "phnn_cartpole", torch), cfg)
+    cc = create_mpc_controller(_load(pHNN_Canonical, CFG, "canonical_cartpole", torch), cfg)
+    rng = np.random.default_rng(11)
+    X = (rng.uniform(-1, 1, size=(3, 40, 4)) * [0.5, 0.2, 0.3, 0.3]).astype(np.float32)
+    eager = [c.compute_control_batch(X[k]) for k in range(3)] + [c.compute_control(X[0, 0])]
+    eager_c = [cc.control_batch(X[k]) for k in range(2)]
+    c.use_graph = cc.use_graph = True
+    graphed = [c.compute_control_batch(X[k]) for k in range(3)] + [c.compute_control(X[0, 0])]
+    graphed_c = [cc.control_batch(X[k]) for k in range(2)]
+    for a, b in zip(eager, graphed):
+        assert np.array_equal(a, b)
+    for a, b in zip(eager_c, graphed_c):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    u_a, info_a = cc.control(ctl["mpc_x0"].copy(), None)  # warm-start path through the graph, against the golden run
+    assert abs(u_a[0] - ctl["can_u_a"][0]) < 2e-4 and np.allclose(info_a["optimization"]["costs"], ctl["can_costs_a"], rtol=1e-5)
+    # latency of the reference's own use (one plant per call), eager vs graph -- printed, not asserted
+    for flag in (False, True):
+        c.use_graph = flag
+        c.compute_control(X[0, 0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(10):
+            c.compute_control(X[0, k])
+        torch.cuda.synchronize()
+        print("compute_control, one plant, H=%d, %d iterations, graph=%s: %.2f ms" % (
+            c.horizon, c.max_iterations, flag, (time.perf_counter() - t0) * 100))
+
+
 def test_adam_kernel_matches_torch_adam_order(torch):
     """K3 against the float32 Adam restatement of the oracle AND against torch.optim.Adam itself on the CPU."""
     from phnn_mpc_amd.engine import RolloutEngine
