@@ -174,12 +174,14 @@ def main():
         ach = flop_k2 / (k2_ms * 1e-3)
         # HBM bytes per K2 launch from the PMC counters: measured in separate rocprofv3 --pmc passes of this same
         # command (profiles/traffic_measured.json), reported only for the configuration it was measured on
-        traffic = None
+        traffic = traffic_k1 = None
         mode = "stash" if ws_stash is not None else "recompute"
         try:
             with open(os.path.join(ROOT, "profiles", "traffic_measured.json")) as f:
                 tm = json.load(f)
-            traffic = tm.get(f"{args.model}:{args.integrator}:B{B}:H{H}:{mode}", {}).get("K2", {}).get("hbm_bytes_per_launch")
+            entry = tm.get(f"{args.model}:{args.integrator}:B{B}:H{H}:{mode}", {})
+            traffic = entry.get("K2", {}).get("hbm_bytes_per_launch")
+            traffic_k1 = entry.get("K1", {}).get("hbm_bytes_per_launch")
         except OSError:
             pass
         mm = eng.matmul_mode
@@ -198,6 +200,10 @@ def main():
             "hbm_algorithmic_GBps": round(bytes_k2 / (k2_ms * 1e-3) / 1e9, 3),
             "hbm_algorithmic_frac": round(bytes_k2 / (k2_ms * 1e-3) / PEAK_HBM, 6),
             "hbm_traffic_frac": None if traffic is None else round(traffic / (k2_ms * 1e-3) / PEAK_HBM, 4),
+            # K1 in stash mode streams the adjoint's workspace out: mostly HBM writes, and it is that stream -- not
+            # its arithmetic (0.87 ms without the stash) -- that sets K1's time
+            "k1_traffic": traffic_k1,
+            "k1_hbm_traffic_frac": None if traffic_k1 is None else round(traffic_k1 / (k1_ms * 1e-3) / PEAK_HBM, 4),
         }
         cpu = None
         if not args.no_cpu_baseline and world == 1:
