@@ -1501,6 +1501,7 @@ struct AdamParams {
   int has_u_bounds;
 };
 
+#ifndef PHNN_ADJOINT_UNIT  // the non-template kernels belong to phnn_mpc.hip only
 __global__ void k_adam(AdamParams p) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= p.count) return;
@@ -1525,3 +1526,4 @@ __global__ void k_best_cost(const float* cost, float* best_cost, long long B) {
   long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B && cost[b] < best_cost[b]) best_cost[b] = cost[b];
 }
+#endif  // PHNN_ADJOINT_UNIT

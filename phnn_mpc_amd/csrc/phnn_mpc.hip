@@ -12,64 +12,11 @@
 #include <string>
 #include <vector>
 
-#include "phnn_kernels.hip.h"
+#include "phnn_variants.h"
 
 namespace {
 
 thread_local std::string g_create_error;
-
-enum Variant {
-  V_NONE = 0,
-  V_PHNN_4_128_FIX,  // cart-pole pHNN (cartpole_mpc_config.yaml)
-  V_PHNN_4_64_FIX,
-  V_PHNN_2_64_GNET,  // pendulum pHNN with learned G (pendulum_config.yaml)
-  V_PHNN_2_64_FIX,
-  V_CANON_128,       // canonical cart-pole pHNN
-  V_CANON_64,
-  V_ODE_2_128,       // ODEFunc(2,1), hidden [128,128,128]
-  V_ODE_2_64,
-  V_ODE_3_128,
-  V_PHNN_4_128_FIX_BF,  // same models, 128x128 products as bf16x3 on the matrix pipe
-  V_CANON_128_BF,
-  V_PHNN_4_128_FIX_H,   // same models, 128x128 products as f16x2 on the matrix pipe
-  V_CANON_128_H,
-  V_ODE_2_128_H,
-  V_ODE_3_128_H,
-  V_ODE_4_128,  // the reference's default ODEFunc(4,1): 5 inputs; f32 only (the f16x2 image would not fit LDS)
-  V_PHNN_4_128_GNET_H,  // remaining (n, G) combinations at width 128, f16x2 only
-  V_PHNN_2_128_GNET_H,
-  V_PHNN_2_128_FIX_H,
-  V_PHNN_4_64_FIX_H,  // f16x2 forms of the 64-wide models
-  V_PHNN_2_64_GNET_H,
-  V_PHNN_2_64_FIX_H,
-  V_CANON_64_H,
-  V_ODE_2_64_H,
-};
-
-using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
-using M_PHNN_4_64_FIX = PhnnModel<4, 64, true>;
-using M_PHNN_2_64_GNET = PhnnModel<2, 64, false>;
-using M_PHNN_2_64_FIX = PhnnModel<2, 64, true>;
-using M_CANON_128 = CanonModel<128>;
-using M_CANON_64 = CanonModel<64>;
-using M_ODE_2_128 = OdeModel<2, 128>;
-using M_ODE_2_64 = OdeModel<2, 64>;
-using M_ODE_3_128 = OdeModel<3, 128>;
-using M_PHNN_4_128_FIX_BF = PhnnModel<4, 128, true, MM_BF16X3>;
-using M_CANON_128_BF = CanonModel<128, MM_BF16X3>;
-using M_PHNN_4_128_FIX_H = PhnnModel<4, 128, true, MM_F16X2>;
-using M_CANON_128_H = CanonModel<128, MM_F16X2>;
-using M_ODE_2_128_H = OdeModel<2, 128, MM_F16X2>;
-using M_ODE_3_128_H = OdeModel<3, 128, MM_F16X2>;
-using M_ODE_4_128 = OdeModel<4, 128>;
-using M_PHNN_4_128_GNET_H = PhnnModel<4, 128, false, MM_F16X2>;
-using M_PHNN_2_128_GNET_H = PhnnModel<2, 128, false, MM_F16X2>;
-using M_PHNN_2_128_FIX_H = PhnnModel<2, 128, true, MM_F16X2>;
-using M_PHNN_4_64_FIX_H = PhnnModel<4, 64, true, MM_F16X2>;
-using M_PHNN_2_64_GNET_H = PhnnModel<2, 64, false, MM_F16X2>;
-using M_PHNN_2_64_FIX_H = PhnnModel<2, 64, true, MM_F16X2>;
-using M_CANON_64_H = CanonModel<64, MM_F16X2>;
-using M_ODE_2_64_H = OdeModel<2, 64, MM_F16X2>;
 
 struct KernelSet {
   void (*fwd[2])(RollParams);
@@ -89,47 +36,30 @@ KernelSet make_set(const char* name) {
   KernelSet k;
   k.fwd[0] = k_rollout_fwd<M, PHNN_INTEG_EULER, false>;
   k.fwd[1] = k_rollout_fwd<M, PHNN_INTEG_RK4, false>;
-  k.grad[0] = k_rollout_grad<M, PHNN_INTEG_EULER, false>;
-  k.grad[1] = k_rollout_grad<M, PHNN_INTEG_RK4, false>;
   k.fwd_stash = k_rollout_fwd<M, PHNN_INTEG_EULER, true>;
-  k.grad_stash = k_rollout_grad<M, PHNN_INTEG_EULER, true>;
   k.stash_floats = M::STASH;
   k.scr_floats = M::SCR;
   k.mfwd = k_model_forward<M>;
-  k.mvjp = k_model_vjp<M>;
   k.img_floats = M::IMG;
   k.name = name;
   return k;
 }
 
 bool kernel_set(int v, KernelSet* k) {
+  GradSet g;
+  if (!phnn_grad_kernels(v, &g)) return false;
   switch (v) {
-    case V_PHNN_4_128_FIX: *k = make_set<M_PHNN_4_128_FIX>("phnn<n=4,hid=128,fixedG>"); return true;
-    case V_PHNN_4_64_FIX: *k = make_set<M_PHNN_4_64_FIX>("phnn<n=4,hid=64,fixedG>"); return true;
-    case V_PHNN_2_64_GNET: *k = make_set<M_PHNN_2_64_GNET>("phnn<n=2,hid=64,Gnet>"); return true;
-    case V_PHNN_2_64_FIX: *k = make_set<M_PHNN_2_64_FIX>("phnn<n=2,hid=64,fixedG>"); return true;
-    case V_CANON_128: *k = make_set<M_CANON_128>("canonical<hid=128>"); return true;
-    case V_CANON_64: *k = make_set<M_CANON_64>("canonical<hid=64>"); return true;
-    case V_ODE_2_128: *k = make_set<M_ODE_2_128>("odefunc<n=2,hid=128>"); return true;
-    case V_ODE_2_64: *k = make_set<M_ODE_2_64>("odefunc<n=2,hid=64>"); return true;
-    case V_ODE_3_128: *k = make_set<M_ODE_3_128>("odefunc<n=3,hid=128>"); return true;
-    case V_PHNN_4_128_FIX_BF: *k = make_set<M_PHNN_4_128_FIX_BF>("phnn<n=4,hid=128,fixedG,bf16x3>"); return true;
-    case V_CANON_128_BF: *k = make_set<M_CANON_128_BF>("canonical<hid=128,bf16x3>"); return true;
-    case V_PHNN_4_128_FIX_H: *k = make_set<M_PHNN_4_128_FIX_H>("phnn<n=4,hid=128,fixedG,f16x2>"); return true;
-    case V_CANON_128_H: *k = make_set<M_CANON_128_H>("canonical<hid=128,f16x2>"); return true;
-    case V_ODE_2_128_H: *k = make_set<M_ODE_2_128_H>("odefunc<n=2,hid=128,f16x2>"); return true;
-    case V_ODE_3_128_H: *k = make_set<M_ODE_3_128_H>("odefunc<n=3,hid=128,f16x2>"); return true;
-    case V_ODE_4_128: *k = make_set<M_ODE_4_128>("odefunc<n=4,hid=128>"); return true;
-    case V_PHNN_4_128_GNET_H: *k = make_set<M_PHNN_4_128_GNET_H>("phnn<n=4,hid=128,Gnet,f16x2>"); return true;
-    case V_PHNN_2_128_GNET_H: *k = make_set<M_PHNN_2_128_GNET_H>("phnn<n=2,hid=128,Gnet,f16x2>"); return true;
-    case V_PHNN_2_128_FIX_H: *k = make_set<M_PHNN_2_128_FIX_H>("phnn<n=2,hid=128,fixedG,f16x2>"); return true;
-    case V_PHNN_4_64_FIX_H: *k = make_set<M_PHNN_4_64_FIX_H>("phnn<n=4,hid=64,fixedG,f16x2>"); return true;
-    case V_PHNN_2_64_GNET_H: *k = make_set<M_PHNN_2_64_GNET_H>("phnn<n=2,hid=64,Gnet,f16x2>"); return true;
-    case V_PHNN_2_64_FIX_H: *k = make_set<M_PHNN_2_64_FIX_H>("phnn<n=2,hid=64,fixedG,f16x2>"); return true;
-    case V_CANON_64_H: *k = make_set<M_CANON_64_H>("canonical<hid=64,f16x2>"); return true;
-    case V_ODE_2_64_H: *k = make_set<M_ODE_2_64_H>("odefunc<n=2,hid=64,f16x2>"); return true;
+#define PHNN_CASE(V, M, NAME) \
+  case V: *k = make_set<M>(NAME); break;
+    PHNN_FOR_EACH_VARIANT(PHNN_CASE)
+#undef PHNN_CASE
     default: return false;
   }
+  k->grad[0] = g.grad[0];
+  k->grad[1] = g.grad[1];
+  k->grad_stash = g.grad_stash;
+  k->mvjp = g.mvjp;
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------

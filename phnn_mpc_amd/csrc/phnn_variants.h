@@ -1,0 +1,93 @@
+// phnn_variants.h -- the kernel variants the library instantiates, shared by the two translation units:
+// phnn_mpc.hip (host side, forward kernels) and phnn_grad.hip (adjoint kernels, compiled with another
+// instruction-scheduling strategy).
+#pragma once
+#include "phnn_kernels.hip.h"
+
+enum Variant {
+  V_NONE = 0,
+  V_PHNN_4_128_FIX,  // cart-pole pHNN (cartpole_mpc_config.yaml)
+  V_PHNN_4_64_FIX,
+  V_PHNN_2_64_GNET,  // pendulum pHNN with learned G (pendulum_config.yaml)
+  V_PHNN_2_64_FIX,
+  V_CANON_128,       // canonical cart-pole pHNN
+  V_CANON_64,
+  V_ODE_2_128,       // ODEFunc(2,1), hidden [128,128,128]
+  V_ODE_2_64,
+  V_ODE_3_128,
+  V_PHNN_4_128_FIX_BF,  // same models, 128x128 products as bf16x3 on the matrix pipe
+  V_CANON_128_BF,
+  V_PHNN_4_128_FIX_H,   // same models, 128x128 products as f16x2 on the matrix pipe
+  V_CANON_128_H,
+  V_ODE_2_128_H,
+  V_ODE_3_128_H,
+  V_ODE_4_128,  // the reference's default ODEFunc(4,1): 5 inputs; f32 only (the f16x2 image would not fit LDS)
+  V_PHNN_4_128_GNET_H,  // remaining (n, G) combinations at width 128, f16x2 only
+  V_PHNN_2_128_GNET_H,
+  V_PHNN_2_128_FIX_H,
+  V_PHNN_4_64_FIX_H,  // f16x2 forms of the 64-wide models
+  V_PHNN_2_64_GNET_H,
+  V_PHNN_2_64_FIX_H,
+  V_CANON_64_H,
+  V_ODE_2_64_H,
+};
+
+using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
+using M_PHNN_4_64_FIX = PhnnModel<4, 64, true>;
+using M_PHNN_2_64_GNET = PhnnModel<2, 64, false>;
+using M_PHNN_2_64_FIX = PhnnModel<2, 64, true>;
+using M_CANON_128 = CanonModel<128>;
+using M_CANON_64 = CanonModel<64>;
+using M_ODE_2_128 = OdeModel<2, 128>;
+using M_ODE_2_64 = OdeModel<2, 64>;
+using M_ODE_3_128 = OdeModel<3, 128>;
+using M_PHNN_4_128_FIX_BF = PhnnModel<4, 128, true, MM_BF16X3>;
+using M_CANON_128_BF = CanonModel<128, MM_BF16X3>;
+using M_PHNN_4_128_FIX_H = PhnnModel<4, 128, true, MM_F16X2>;
+using M_CANON_128_H = CanonModel<128, MM_F16X2>;
+using M_ODE_2_128_H = OdeModel<2, 128, MM_F16X2>;
+using M_ODE_3_128_H = OdeModel<3, 128, MM_F16X2>;
+using M_ODE_4_128 = OdeModel<4, 128>;
+using M_PHNN_4_128_GNET_H = PhnnModel<4, 128, false, MM_F16X2>;
+using M_PHNN_2_128_GNET_H = PhnnModel<2, 128, false, MM_F16X2>;
+using M_PHNN_2_128_FIX_H = PhnnModel<2, 128, true, MM_F16X2>;
+using M_PHNN_4_64_FIX_H = PhnnModel<4, 64, true, MM_F16X2>;
+using M_PHNN_2_64_GNET_H = PhnnModel<2, 64, false, MM_F16X2>;
+using M_PHNN_2_64_FIX_H = PhnnModel<2, 64, true, MM_F16X2>;
+using M_CANON_64_H = CanonModel<64, MM_F16X2>;
+using M_ODE_2_64_H = OdeModel<2, 64, MM_F16X2>;
+
+struct GradSet {
+  void (*grad[2])(RollParams);     // Euler, RK4: recompute the tape
+  void (*grad_stash)(RollParams);  // Euler, K2 reads the tape K1 stashed
+  void (*mvjp)(PointParams);
+};
+
+// defined in phnn_grad.hip
+bool phnn_grad_kernels(int variant, GradSet* g);
+
+#define PHNN_FOR_EACH_VARIANT(X)                                                                                       \
+  X(V_PHNN_4_128_FIX, M_PHNN_4_128_FIX, "phnn<n=4,hid=128,fixedG>") \
+  X(V_PHNN_4_64_FIX, M_PHNN_4_64_FIX, "phnn<n=4,hid=64,fixedG>") \
+  X(V_PHNN_2_64_GNET, M_PHNN_2_64_GNET, "phnn<n=2,hid=64,Gnet>") \
+  X(V_PHNN_2_64_FIX, M_PHNN_2_64_FIX, "phnn<n=2,hid=64,fixedG>") \
+  X(V_CANON_128, M_CANON_128, "canonical<hid=128>") \
+  X(V_CANON_64, M_CANON_64, "canonical<hid=64>") \
+  X(V_ODE_2_128, M_ODE_2_128, "odefunc<n=2,hid=128>") \
+  X(V_ODE_2_64, M_ODE_2_64, "odefunc<n=2,hid=64>") \
+  X(V_ODE_3_128, M_ODE_3_128, "odefunc<n=3,hid=128>") \
+  X(V_PHNN_4_128_FIX_BF, M_PHNN_4_128_FIX_BF, "phnn<n=4,hid=128,fixedG,bf16x3>") \
+  X(V_CANON_128_BF, M_CANON_128_BF, "canonical<hid=128,bf16x3>") \
+  X(V_PHNN_4_128_FIX_H, M_PHNN_4_128_FIX_H, "phnn<n=4,hid=128,fixedG,f16x2>") \
+  X(V_CANON_128_H, M_CANON_128_H, "canonical<hid=128,f16x2>") \
+  X(V_ODE_2_128_H, M_ODE_2_128_H, "odefunc<n=2,hid=128,f16x2>") \
+  X(V_ODE_3_128_H, M_ODE_3_128_H, "odefunc<n=3,hid=128,f16x2>") \
+  X(V_ODE_4_128, M_ODE_4_128, "odefunc<n=4,hid=128>") \
+  X(V_PHNN_4_128_GNET_H, M_PHNN_4_128_GNET_H, "phnn<n=4,hid=128,Gnet,f16x2>") \
+  X(V_PHNN_2_128_GNET_H, M_PHNN_2_128_GNET_H, "phnn<n=2,hid=128,Gnet,f16x2>") \
+  X(V_PHNN_2_128_FIX_H, M_PHNN_2_128_FIX_H, "phnn<n=2,hid=128,fixedG,f16x2>") \
+  X(V_PHNN_4_64_FIX_H, M_PHNN_4_64_FIX_H, "phnn<n=4,hid=64,fixedG,f16x2>") \
+  X(V_PHNN_2_64_GNET_H, M_PHNN_2_64_GNET_H, "phnn<n=2,hid=64,Gnet,f16x2>") \
+  X(V_PHNN_2_64_FIX_H, M_PHNN_2_64_FIX_H, "phnn<n=2,hid=64,fixedG,f16x2>") \
+  X(V_CANON_64_H, M_CANON_64_H, "canonical<hid=64,f16x2>") \
+  X(V_ODE_2_64_H, M_ODE_2_64_H, "odefunc<n=2,hid=64,f16x2>")

@@ -16,7 +16,7 @@ def pytest_configure(config):
     import subprocess
     lib = os.path.join(ROOT, "phnn_mpc_amd", "csrc", "libphnn_mpc.so")
     if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
-        subprocess.check_call(["make", "-C", os.path.dirname(lib), "-s"])
+        subprocess.check_call(["make", "-j2", "-C", os.path.dirname(lib), "-s"])
 
 
 @pytest.fixture(scope="session")

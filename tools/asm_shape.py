@@ -9,8 +9,12 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 asm = "/tmp/phnn_shape.s"
+key = sys.argv[1]
+adjoint = "grad" in key or "vjp" in key  # the adjoint kernels live in phnn_grad.hip, built with the max-ILP scheduler
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                "--cuda-device-only", "-S", "-o", asm, os.path.join(root, "phnn_mpc_amd/csrc/phnn_mpc.hip")],
+                "--cuda-device-only", "-S", "-o", asm,
+                os.path.join(root, "phnn_mpc_amd/csrc", "phnn_grad.hip" if adjoint else "phnn_mpc.hip")]
+               + (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if adjoint else []),
                check=True, stderr=subprocess.DEVNULL)
 s = open(asm).read()
 key = sys.argv[1]

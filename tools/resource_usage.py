@@ -6,10 +6,12 @@ import subprocess
 import sys
 
 csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "phnn_mpc_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-       "--cuda-device-only", "-c", "-o", "/dev/null", "phnn_mpc.hip", "-Rpass-analysis=kernel-resource-usage"]
-cmd += sys.argv[1:]
-out = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True).stderr
+out = ""
+for src, extra in (("phnn_mpc.hip", []), ("phnn_grad.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])):  # as the Makefile
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+           "--cuda-device-only", "-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"] + extra
+    cmd += sys.argv[1:]
+    out += subprocess.run(cmd, cwd=csrc, capture_output=True, text=True).stderr
 rows, cur = [], {}
 for line in out.splitlines():
     m = re.search(r"remark: (.*?) \[-Rpass", line)
