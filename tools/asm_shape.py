@@ -14,7 +14,7 @@ adjoint = "grad" in key or "vjp" in key  # the adjoint kernels live in phnn_grad
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                 "--cuda-device-only", "-S", "-o", asm,
                 os.path.join(root, "phnn_mpc_amd/csrc", "phnn_grad.hip" if adjoint else "phnn_mpc.hip")]
-               + (["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if adjoint else []),
+               + (["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"] if adjoint else []),
                check=True, stderr=subprocess.DEVNULL)
 s = open(asm).read()
 key = sys.argv[1]

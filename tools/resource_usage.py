@@ -7,7 +7,7 @@ import sys
 
 csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "phnn_mpc_amd", "csrc")
 out = ""
-for src, extra in (("phnn_mpc.hip", []), ("phnn_grad.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])):  # as the Makefile
+for src, extra in (("phnn_mpc.hip", []), ("phnn_grad.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"])):  # as the Makefile
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
            "--cuda-device-only", "-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"] + extra
     cmd += sys.argv[1:]
