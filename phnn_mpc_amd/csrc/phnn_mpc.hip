@@ -663,7 +663,7 @@ int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_float
   }
   e = hipMemcpy(h->d_img, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
-    hipFree(h->d_img);
+    (void)hipFree(h->d_img);
     delete h;
     return hip_fail(nullptr, e, "hipMemcpy(weights image)");
   }
@@ -673,7 +673,7 @@ int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_float
 
 int phnn_destroy(phnn_handle* h) {
   if (!h) return PHNN_OK;
-  if (h->d_img) hipFree(h->d_img);
+  if (h->d_img) (void)hipFree(h->d_img);
   delete h;
   return PHNN_OK;
 }
