@@ -577,7 +577,7 @@ struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int oW3B = oW3 + HID;         // [HID]   w3 * Sb (g2 = w3 (1 - a2^2), fed to the transposed product)
   static constexpr int oW3S = oW3B + HID;        // [HID]   w3 * Sb / S (used by the Hessian-vector product)
   static constexpr int oW1T = oW3S + HID;        // [4][LR] rows c = W1[:,c] / (S Sb)
-  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 1 / k1, 1 / S), k1 = factor folded into W1, b1
+  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 1 / k1, 0), k1 = factor folded into W1, b1
   static constexpr int SIZE = oB3 + 4;
 };
 
@@ -607,9 +607,7 @@ struct HTape {
   Act<HID / 16> a1, a2, q1;  // activations, and q1 = W2^T g2 (before the (1-a1^2) factor)
 };
 
-// PRE (K1 with a stash): the tape is left in the form the Hessian-vector product consumes -- a2 is replaced by
-// e2 = w3 a2 (1 - a2^2) / S and q1 by q1 a1 -- so K2 multiplies once where it would load w3 and multiply four times.
-template <int HID, bool WANT_H, int MM = MM_F32, bool PRE = false>
+template <int HID, bool WANT_H, int MM = MM_F32>
 DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hval) {
   using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
@@ -656,7 +654,6 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
     }
     f32x4 w3b = *reinterpret_cast<const f32x4*>(L + Y::oW3B + 16 * t + 4 * ln.q);
     g.v[t] = w3b * dtanh(tp.a2.v[t]);
-    if (PRE) tp.a2.v[t] = (g.v[t] * tp.a2.v[t]) * L[Y::oB3 + 3];  // oB3[3] = 1 / S
   }
   if (WANT_H) Hval = reduce_q(s) + L[Y::oB3];
   zero_act<T>(tp.q1);
@@ -672,10 +669,7 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
     sq_bwd<T, T>(tp.q1, L + Y::oW2, ln, g);
   }
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    g.v[t] = tp.q1.v[t] * dtanh(tp.a1.v[t]);
-    if (PRE) tp.q1.v[t] = tp.q1.v[t] * tp.a1.v[t];
-  }
+  for (int t = 0; t < T; ++t) g.v[t] = tp.q1.v[t] * dtanh(tp.a1.v[t]);
   return to4_rep<T>(L + Y::oW1T, ln, g);
 }
 
@@ -691,7 +685,7 @@ DEV void hnet_layer1(const float* L, Lane ln, f32x4 z, Act<HID / 16>& a1) {
 
 // Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
 // (q1 is overwritten) to keep the live register set at five activation vectors.
-template <int HID, int MM = MM_F32, bool PRE = false>
+template <int HID, int MM = MM_F32>
 DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
@@ -713,7 +707,7 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   // rest of this function works with -1/2 of the true quantities and the factor is restored on the final 4-vector.
   // Second term of gdot1 folded now, adot1 dies after the product.
 #pragma unroll
-  for (int t = 0; t < T; ++t) tp.q1.v[t] = PRE ? tp.q1.v[t] * ad1.v[t] : tp.q1.v[t] * (tp.a1.v[t] * ad1.v[t]);
+  for (int t = 0; t < T; ++t) tp.q1.v[t] = tp.q1.v[t] * (tp.a1.v[t] * ad1.v[t]);
   zero_act<T>(w);
   if (MM == MM_BF16X3) {
     Split3<T> sp;
@@ -729,14 +723,10 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   keep_lds_reads_local();
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    if (PRE) {  // tp.a2 holds e2 = (w3 / S) a2 (1 - a2^2)
-      w.v[t] = tp.a2.v[t] * w.v[t];
-    } else {
-      f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3S + 16 * t + 4 * ln.q);  // w3 / S: w holds S * zdot2
-      f32x4 a2 = tp.a2.v[t];
-      f32x4 ad2 = dtanh(a2) * w.v[t];
-      w.v[t] = w3 * (a2 * ad2);  // -gdot2 / 2
-    }
+    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3S + 16 * t + 4 * ln.q);  // w3 / S: w holds S * zdot2
+    f32x4 a2 = tp.a2.v[t];
+    f32x4 ad2 = dtanh(a2) * w.v[t];
+    w.v[t] = w3 * (a2 * ad2);  // -gdot2 / 2
   }
   Act<T> qd;
   zero_act<T>(qd);
@@ -862,8 +852,7 @@ struct PhnnModel {
   static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
   static constexpr int IMG = oG + 4;
 
-  // floats one wave stashes per step for the adjoint: e2 = w3 a2 (1-a2^2) / S and q1 a1 (T x 256 each, the forms the
-  // Hessian-vector product consumes) + dH (16 x 4); a1 is recomputed
+  // floats one wave stashes per step for the adjoint: a2, q1 (T x 256 each) + dH (16 x 4); a1 is recomputed
   static constexpr int STASH = 2 * T * 256 + 64;
 
   // dx = (Jeff - S S^T) dH + G u, with S = sym(R_raw).  stash != null: keep the H_net tape for K2.
@@ -871,7 +860,7 @@ struct PhnnModel {
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H, MM, ST>(L + oH, ln, x, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, x, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a2);
       store_act<T>(stash + T * 256, ln, tp.q1);
@@ -999,7 +988,7 @@ struct PhnnModel {
       for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[j][k], Stl[k], acc);
       v[j] = acc;
     }
-    xbar = xb + hnet_hvp<HID, MM, ST>(L + oH, ln, tp, v);
+    xbar = xb + hnet_hvp<HID, MM>(L + oH, ln, tp, v);
   }
 };
 
@@ -1026,7 +1015,7 @@ struct CanonModel {
     float bc = b * cs;
     f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H, MM, ST>(L + oH, ln, z, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, z, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a2);
       store_act<T>(stash + T * 256, ln, tp.q1);
@@ -1073,7 +1062,7 @@ struct CanonModel {
     float mb11 = lam[1] * z[3] + lam[3] * dp1;
     f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
     ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
-    f32x4 zb = hnet_hvp<HID, MM, ST>(L + oH, ln, tp, v);
+    f32x4 zb = hnet_hvp<HID, MM>(L + oH, ln, tp, v);
     zb[2] += pb0;
     zb[3] += pb1;
     float bcb = zb[2] * y[3] + zb[3] * y[2];

@@ -312,7 +312,6 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   dst[Y::oB3] = b3[0];
   dst[Y::oB3 + 1] = 2.8853900817779268f / S;
   dst[Y::oB3 + 2] = 1.0f / k1;
-  dst[Y::oB3 + 3] = 1.0f / S;
   return p;
 }
 
