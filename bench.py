@@ -46,8 +46,8 @@ SPLIT_PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=65536, help="rollouts per GPU")
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--model", default="phnn_cartpole",
