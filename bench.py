@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--preheat", type=int, default=0,
+                    help="extra untimed passes before the W warmup steps (same count on every rank; reported as "
+                         "preheat_steps).  Off by default: the first ~0.5 s after the idle clock run a few percent above "
+                         "the rate the part sustains at its power cap (28.4 M/s over 30 s), so preheating a short run "
+                         "would flatter it")
     ap.add_argument("--batch", type=int, default=65536, help="rollouts per GPU")
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--model", default="phnn_cartpole",
@@ -142,7 +147,7 @@ def main():
     nstash = eng.workspace_bytes(B, H, integ) if (eng.use_stash and not args.no_stash) else 0
     ws_stash = torch.empty(nstash, dtype=torch.uint8, device=dev) if nstash > 0 else None
 
-    for _ in range(args.warmup):
+    for _ in range(args.preheat + args.warmup):
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -210,7 +215,7 @@ def main():
             cpu = cpu_baseline(w, cost, x0_h, U_h, args.integrator, dt, args.cpu_sample)
         out = {
             "metric": "pHNN-MPC rollouts+grads/sec, cartpole H=50 batch=65536", "value": round(value, 1),
-            "unit": "rollouts+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "rollouts+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_steps": args.preheat,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} (seed-0 fixture weights) {args.integrator} H={H} "
