@@ -61,6 +61,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stash", action="store_true", help="K2 recomputes the forward tape instead of reading K1's")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="rollouts timed on the host for cpu_baseline")
+    ap.add_argument("--matmul", default=None, choices=["default", "f32", "bf16x3", "f16x2"],
+                    help="how the hidden x hidden products are evaluated (default: PHNN_MATMUL or the library default)")
+    ap.add_argument("--no-other-modes", action="store_true",
+                    help="skip the short timed loops of the other matmul modes (other_modes on the JSON line)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch rollouts per GPU (default); strong: --global-batch rollouts split over the GPUs")
+    ap.add_argument("--global-batch", type=int, default=65536, help="total rollouts with --scaling strong")
+    ap.add_argument("--config", default=None, choices=["headline", "config4"],
+                    help="named workloads: headline = H=50, 65536 rollouts per GPU; config4 = BASELINE config 4, "
+                         "2^20 rollouts over 8 GPUs = 131072 per GPU")
     return ap.parse_args()
 
 
@@ -98,81 +108,128 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     from phnn_mpc_amd import _capi
+    from phnn_mpc_amd.distributed import shard_bounds
     from phnn_mpc_amd.engine import RolloutEngine
+    import ctypes as C
     gold = os.path.join(ROOT, "tests", "golden")
     with np.load(os.path.join(gold, f"weights_{args.model}.npz")) as z:
         w = {k: z[k] for k in z.files}
-    eng = RolloutEngine(w, dev)
-    n, B, H = eng.n, args.batch, args.horizon
+    eng = RolloutEngine(w, dev, matmul=args.matmul)
+    if args.config == "config4":
+        args.batch = 131072
+    if args.scaling == "strong":  # fixed total work: the global batch is split contiguously over the ranks
+        lo, hi = shard_bounds(args.global_batch, world, rank)
+        B, B_pad, total = hi - lo, -(-args.global_batch // world), args.global_batch
+    else:
+        B, B_pad, total = args.batch, args.batch, world * args.batch
+    n, H = eng.n, args.horizon
     cart = n == 4
     dt = 0.02 if cart else 0.05
     umax = 15.0 if cart else 2.0
     cost = _capi.make_cost(n, 1, [10.0, 200.0, 1.0, 10.0] if cart else [10.0, 1.0], [0.01], None, -umax, umax)
-    x0_h, U_h = synthetic_inputs(n, B, H, rank, 5.0 if cart else 2.0)
-    x0 = torch.from_numpy(x0_h).to(dev)
-    U = torch.from_numpy(U_h).to(dev)
-    ws = {}
-    gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if world > 1 else None
-
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        eng.lib.phnn_rollout_fwd(eng.h, eng._p(x0), eng._p(U), B, H, cost_ref, integ, float(dt), eng._p(ws_cost),
-                                 eng._p(ws_traj), eng._p(ws_stash), eng._stream())
-        c = ws_cost
-        if ev is not None:
-            ev[1].record()
-        work = None
-        if world > 1 and backend == "nccl":  # costs are final after K1: the all-gather runs on RCCL's stream under K2
-            work = dist.all_gather_into_tensor(gathered, c, async_op=True)
-        eng.lib.phnn_rollout_grad(eng.h, eng._p(x0), eng._p(U), B, H, cost_ref, integ, float(dt), eng._p(ws_traj),
-                                  eng._p(ws_stash), eng._p(ws_gu), None, eng._stream())
-        if ev is not None:
-            ev[2].record()
-        if world > 1:
-            if work is not None:
-                work.wait()  # stream-level wait: the next step's K1 must not overwrite c before the gather has read it
-            else:  # rehearsal backend: collectives on host copies
-                parts = [torch.empty(B, dtype=torch.float32) for _ in range(world)]
-                dist.all_gather(parts, c.cpu())
-                gathered.copy_(torch.cat(parts))
-        return c
-
-    import ctypes as C
     cost_ref = C.byref(cost)
     integ = _capi.INTEGRATORS[args.integrator]
-    ws_traj = torch.empty(B, H + 1, n, dtype=torch.float32, device=dev)
-    ws_gu = torch.empty(B, H, 1, dtype=torch.float32, device=dev)
-    ws_cost = torch.empty(B, dtype=torch.float32, device=dev)
-    nstash = eng.workspace_bytes(B, H, integ) if (eng.use_stash and not args.no_stash) else 0
-    ws_stash = torch.empty(nstash, dtype=torch.uint8, device=dev) if nstash > 0 else None
+    x0_h, U_h = synthetic_inputs(n, max(B, 1), H, rank, 5.0 if cart else 2.0)
+    x0 = torch.from_numpy(x0_h).to(dev)
+    U = torch.from_numpy(U_h).to(dev)
 
-    for _ in range(args.preheat + args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        c_last = step(evs[k])
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    k1_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    k2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
-    assert torch.isfinite(c_last).all(), "non-finite cost in the bench workload"
+    class Workload:
+        """One rank's share of the hot path: K1, (all-gather of the costs), K2 on Bk rollouts resident in HBM."""
+
+        def __init__(self, engine, Bk, Bk_pad, stash=True):
+            self.eng, self.B = engine, Bk
+            self.traj = torch.empty(Bk, H + 1, n, dtype=torch.float32, device=dev)
+            self.gu = torch.empty(Bk, H, 1, dtype=torch.float32, device=dev)
+            self.c_pad = torch.zeros(Bk_pad, dtype=torch.float32, device=dev)  # K1 writes the first Bk entries
+            self.cost = self.c_pad[:Bk]
+            nst = engine.workspace_bytes(Bk, H, integ) if (engine.use_stash and stash) else 0
+            self.stash = torch.empty(nst, dtype=torch.uint8, device=dev) if nst > 0 else None
+            self.gathered = torch.empty(world * Bk_pad, dtype=torch.float32, device=dev) if world > 1 else None
+
+        def step(self, ev=None):
+            e, Bk = self.eng, self.B
+            if ev is not None:
+                ev[0].record()
+            e.lib.phnn_rollout_fwd(e.h, e._p(x0), e._p(U), Bk, H, cost_ref, integ, float(dt), e._p(self.cost),
+                                   e._p(self.traj), e._p(self.stash), e._stream())
+            if ev is not None:
+                ev[1].record()
+            work = None
+            if world > 1 and backend == "nccl":  # costs are final after K1: the gather runs on RCCL's stream under K2
+                work = dist.all_gather_into_tensor(self.gathered, self.c_pad, async_op=True)
+            e.lib.phnn_rollout_grad(e.h, e._p(x0), e._p(U), Bk, H, cost_ref, integ, float(dt), e._p(self.traj),
+                                    e._p(self.stash), e._p(self.gu), None, e._stream())
+            if ev is not None:
+                ev[2].record()
+            if world > 1:
+                if work is not None:
+                    work.wait()  # stream-level wait: the next K1 must not overwrite the costs before the gather read them
+                else:  # rehearsal backend: collectives on host copies
+                    parts = [torch.empty(self.c_pad.numel(), dtype=torch.float32) for _ in range(world)]
+                    dist.all_gather(parts, self.c_pad.cpu())
+                    self.gathered.copy_(torch.cat(parts))
+            return self.cost
+
+        def timed(self, steps, warmup):
+            """W untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; max over ranks."""
+            for _ in range(warmup):
+                self.step()
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+            t0 = time.perf_counter()
+            for k in range(steps):
+                c_last = self.step(evs[k])
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            k1 = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+            k2 = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+            assert torch.isfinite(c_last).all(), "non-finite cost in the bench workload"
+            return el, k1, k2
+
+    main_wl = Workload(eng, B, B_pad, stash=not args.no_stash)
+    ws_stash = main_wl.stash
+    elapsed, k1_ms, k2_ms = main_wl.timed(args.steps, args.preheat + args.warmup)
+
+    # strong-scaling figure next to the weak one (N > 1): the SAME global batch of 65536 split over the ranks
+    strong = None
+    if world > 1 and args.scaling == "weak":
+        lo, hi = shard_bounds(args.global_batch, world, rank)
+        Bs, Bs_pad = hi - lo, -(-args.global_batch // world)
+        if Bs <= B:
+            del main_wl
+            torch.cuda.empty_cache()
+            ks = max(min(args.steps, 50), 1)
+            el_s, k1s, k2s = Workload(eng, Bs, Bs_pad, stash=not args.no_stash).timed(ks, 3)
+            strong = {"global_batch": args.global_batch, "batch_per_gpu": Bs_pad, "steps": ks,
+                      "value": round(args.global_batch * ks / el_s, 1), "ms_per_step": round(1e3 * el_s / ks, 4),
+                      "k1_launch_ms": round(k1s, 4), "k2_launch_ms": round(k2s, 4)}
+    # the 24-bit-exact product modes, short timed loops in the same run (single GPU only)
+    other_modes = None
+    if world == 1 and not args.no_other_modes and args.model in ("phnn_cartpole", "canonical_cartpole"):
+        other_modes = {}
+        for mode in ("bf16x3", "f32"):
+            if mode == eng.matmul_mode:
+                continue
+            e2 = RolloutEngine(w, dev, matmul=mode)
+            ko = max(min(args.steps, 10), 1)
+            el_o, k1o, k2o = Workload(e2, B, B_pad, stash=not args.no_stash).timed(ko, 2)
+            other_modes[mode] = {"value": round(B * ko / el_o, 1), "steps": ko, "k1_launch_ms": round(k1o, 4),
+                                 "k2_launch_ms": round(k2o, 4), "kernel_variant": e2.variant}
+            e2.close()
 
     if rank == 0:
         stages = 4 if args.integrator == "rk4" else 1
-        value = world * B * args.steps / elapsed
+        value = total * args.steps / elapsed
         flop_k2 = B * H * stages * FLOP_VJP  # algorithmic, per launch
         flop_job = B * H * stages * (FLOP_FWD + FLOP_VJP)
         bytes_k2 = B * (4 * (n + 2 * H) + 4)  # SURVEY 8d: 4(n + 2 H m) + 4 per rollout with gradient
@@ -198,6 +255,7 @@ def main():
                            f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS[mm]} split products per f32 product ({mm})"),
             "vs_f32_mfma_peak": round(ach / PEAK_F32_MFMA, 4),
             "traffic_unit": "HBM bytes per K2 launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+            "traffic_source": "profiles/traffic_measured.json (separate rocprofv3 --pmc passes of this command; not observed in this run)",
             "launch_ms": round(k2_ms, 4), "k1_launch_ms": round(k1_ms, 4),
             "job_tflops": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / 1e12, 3),
             "job_frac": round(flop_job / ((k1_ms + k2_ms) * 1e-3) / peak, 4),
@@ -210,34 +268,67 @@ def main():
             "k1_traffic": traffic_k1,
             "k1_hbm_traffic_frac": None if traffic_k1 is None else round(traffic_k1 / (k1_ms * 1e-3) / PEAK_HBM, 4),
         }
-        cpu = None
+        cpu = cpu_torch = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(w, cost, x0_h, U_h, args.integrator, dt, args.cpu_sample)
+            if args.model == "phnn_cartpole" and args.integrator == "euler":
+                cpu_torch = cpu_baseline_torch(w, x0_h, U_h, dt, umax)
         out = {
             "metric": "pHNN-MPC rollouts+grads/sec, cartpole H=50 batch=65536", "value": round(value, 1),
             "unit": "rollouts+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_steps": args.preheat,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} (seed-0 fixture weights) {args.integrator} H={H} "
                                    f"B={B}/GPU: rollout + stage cost (K1) + control gradient (K2)"
                                    + (" + RCCL all-gather of costs" if world > 1 else ""),
                        "k2_mode": "stash" if ws_stash is not None else "recompute", "matmul": eng.matmul_mode,
-                       "kernel_variant": eng.variant, "horizon": H, "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"shard{world}"},
+                       "kernel_variant": eng.variant, "horizon": H, "batch_per_gpu": B_pad, "global_batch": total, "parallelism": f"shard{world}"},
             "roofline": roof,
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if cpu_torch is not None:
+            out["cpu_baseline_torch"] = cpu_torch
+        if other_modes:
+            out["other_modes"] = other_modes
+        if strong is not None:
+            out["strong_scaling"] = strong
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_cpu():
+    """(usable cores, CPU model string).  Cores = scheduler affinity, capped by the cgroup CPU quota when one is set
+    (the GPU box gives one GPU's job a share of the host); no hard-coded cap."""
+    cores = len(os.sched_getaffinity(0))
+    src = "sched_getaffinity"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            quota = max(int(int(q) / int(per)), 1)
+            if quota < cores:
+                cores, src = quota, "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return cores, src, model
 
 
 def cpu_baseline(w, cost, x0_h, U_h, integ, dt, sample):
     """Time the float32 CPU oracle (test infrastructure, used here only as the measured baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
-    # the GPU box gives one GPU's job a 16-core share of the host whatever os.cpu_count() says
-    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)
+    cores, src, model = host_cpu()
     m = ol.OracleModel(w, "f32")
     t = time.perf_counter()
     m.rollout(x0_h[:256], U_h[:256], cost, integ, dt, traj=False, nthreads=cores)  # warm + pilot
@@ -248,8 +339,31 @@ def cpu_baseline(w, cost, x0_h, U_h, integ, dt, sample):
     for _ in range(reps):
         m.rollout(x0_h[:S], U_h[:S], cost, integ, dt, traj=False, nthreads=cores)
     el = time.perf_counter() - t
-    return {"value": round(reps * S / el, 1), "unit": "rollouts+grads/s", "cores": cores, "kind": "port",
+    return {"value": round(reps * S / el, 1), "unit": "rollouts+grads/s", "cores": cores, "cores_source": src,
+            "cpu_model": model, "kind": "port",
             "sample": f"first {S} rollouts of the same batch x{reps}, float32 C oracle, OpenMP static over rollouts, {el:.1f} s"}
+
+
+def cpu_baseline_torch(w, x0_h, U_h, dt, umax):
+    """BASELINE.md section 4, second baseline: the stock PyTorch-CPU restatement of the batched oracle
+    (oracle/torch_oracle.py: torch ops + autograd, as the reference computes it), all host cores."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from torch_oracle import TorchPhnn
+    cores, src, model = host_cpu()
+    torch.set_num_threads(cores)
+    m = TorchPhnn(w, torch.float32)
+    args = ([10.0, 200.0, 1.0, 10.0], 0.01, [0.0, 0.0, 0.0, 0.0], -umax, umax, dt)
+    t = time.perf_counter()
+    m.rollout_cost_grad(x0_h[:512], U_h[:512], *args)
+    pilot = 512 / max(time.perf_counter() - t, 1e-6)
+    S = int(min(max(2048, 8.0 * pilot), 8192, x0_h.shape[0]))  # ~8 s of CPU work, bounded (autograd graph memory)
+    t = time.perf_counter()
+    m.rollout_cost_grad(x0_h[:S], U_h[:S], *args)
+    el = time.perf_counter() - t
+    return {"value": round(S / el, 1), "unit": "rollouts+grads/s", "cores": cores, "cores_source": src, "cpu_model": model,
+            "kind": "port", "sample": f"first {S} rollouts of the same batch, float32 torch ops + autograd "
+                                      f"(oracle/torch_oracle.py), torch.set_num_threads({cores}), {el:.1f} s"}
 
 
 if __name__ == "__main__":

@@ -14,7 +14,9 @@
  *     the caller (e.g. torch tensor.data_ptr()); the library owns only the packed weights in a handle;
  *   - every launch is asynchronous on the hipStream_t passed as `void* stream` (NULL = default stream);
  *     no entry point synchronises the device or allocates on the hot path;
- *   - one handle per (model, device); calls on one handle are not re-entrant from several host threads.
+ *   - one handle per (model, device); calls on one handle are not re-entrant from several host threads;
+ *   - a call leaves the calling thread's current HIP device as it found it (the handle's device is made current
+ *     only for the duration of the call).
  */
 #ifndef PHNN_MPC_H
 #define PHNN_MPC_H
@@ -26,8 +28,9 @@
 extern "C" {
 #endif
 
-#define PHNN_MAX_N 8      /* state dimension limit  */
-#define PHNN_MAX_M 4      /* input dimension limit  */
+#define PHNN_MAX_N 8      /* state dimension limit (array bound of the structs below)  */
+#define PHNN_MAX_M 4      /* array bound for R in phnn_cost; see PHNN_SUPPORTED_M        */
+#define PHNN_SUPPORTED_M 1 /* input dimension the gfx950 kernels are instantiated for: phnn_create refuses m > 1 */
 #define PHNN_MAX_LAYERS 4 /* hidden layers per MLP  */
 
 typedef enum {
@@ -46,6 +49,16 @@ typedef enum {
 } phnn_model_kind;
 
 typedef enum { PHNN_INTEG_EULER = 0, PHNN_INTEG_RK4 = 1 } phnn_integrator; /* src/integrators.py:13-84 */
+
+/* Activation of every MLP in the model (src/NN.py:6-40 takes any nn.Module class; src/pHNN.py:41 resolves it by
+ * name).  Only Tanh has kernels -- the one every shipped config selects; anything else is refused by phnn_create so
+ * that a checkpoint trained with another activation (same keys, same shapes) cannot be run as a Tanh network. */
+typedef enum { PHNN_ACT_TANH = 0, PHNN_ACT_OTHER = 1 } phnn_activation;
+
+/* How the hidden x hidden products are evaluated.  DEFAULT: f16x2 for 128-wide models, f32 for
+ * narrower ones (f16x2 on the 64-wide trained pendulum model is known to exceed the stated tolerance in long
+ * rollouts: phnn_create_ex refuses it there unless force_matmul is set). */
+typedef enum { PHNN_MATMUL_DEFAULT = 0, PHNN_MATMUL_F32 = 1, PHNN_MATMUL_BF16X3 = 2, PHNN_MATMUL_F16X2 = 3 } phnn_matmul_mode;
 
 /* MLP shape: Linear(in,h[0]) tanh ... Linear(h[depth-1],out); src/NN.py:6-40 with activation nn.Tanh,
  * bias=True, dropout=0, layer_norm=False (the only variant any shipped config selects). */
@@ -70,7 +83,16 @@ typedef struct {
   phnn_mlp_shape h_net; /* H_net, or the ODEFunc network */
   phnn_mlp_shape r_net; /* PHNN only */
   phnn_mlp_shape g_net; /* PHNN with fixed_G == 0 only */
+  int32_t activation;   /* phnn_activation; must be PHNN_ACT_TANH */
 } phnn_desc;
+
+/* Options of phnn_create_ex; zero-initialise for the defaults. */
+typedef struct {
+  int32_t matmul_mode;  /* phnn_matmul_mode */
+  int32_t force_matmul; /* 1: accept matmul_mode even where it is known to miss the stated tolerance (64-wide + f16x2) */
+  int32_t max_waves;    /* waves per workgroup cap, 1..8; 0 = default (8).  4 = one wave per SIMD (diagnostics) */
+  int32_t reserved[5];  /* must be zero */
+} phnn_options;
 
 /* Stage cost of both controllers:
  *   cost = sum_{t=0..H} (x_t-x*)^T Q (x_t-x*) + sum_{t<H} u_t^T R u_t
@@ -97,6 +119,13 @@ typedef struct phnn_handle phnn_handle;
  * load_state_dict (src/pHNN.py:13-38, scripts/run_cartpole_mpc.py:27-54). */
 int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_floats, int device,
                 phnn_handle** out);
+/* Same with explicit options (NULL = defaults).  The library reads no environment variable: the Python host maps
+ * PHNN_MATMUL / PHNN_MAX_WAVES to this struct as its own default (phnn_mpc_amd/engine.py). */
+int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_floats, int device,
+                   const phnn_options* opt, phnn_handle** out);
+/* Replace the weights of an existing handle (same description): re-packs and re-uploads the LDS image on `stream`
+ * order.  What load_state_dict / an optimizer step on the reference module amounts to for the engine. */
+int phnn_update_weights(phnn_handle* h, const float* weights_host, size_t n_floats, void* stream);
 int phnn_destroy(phnn_handle* h);
 /* Message of the last failing call on this handle (or of the last failing phnn_create if h == NULL). */
 const char* phnn_last_error(const phnn_handle* h);
@@ -160,6 +189,33 @@ int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* e
                    int32_t step, const float* cost_dev, float* best_cost_dev, float* best_u_dev, int64_t per,
                    float u_min, float u_max, int32_t has_u_bounds, void* stream);
 
+/* ---- the plant on the other side of the path ------------------------------------------
+ * Ground-truth cart-pole of src/cartpole_simulator.py:63-112: float64, explicit Euler, the standard cart-pole
+ * equations in the reference's operation order; termination |x| > x_limit or |theta| > theta_limit.  Defaults of
+ * the reference: gravity 9.8, masscart 1.0, masspole 0.1, length 0.5 (half-length), dt 0.02, limits 10.0 / 0.5. */
+typedef struct {
+  double gravity, masscart, masspole, length, dt, x_limit, theta_limit;
+} phnn_plant;
+
+/* One plant step for B plants, everything resident on the device (no host round trip in a closed loop):
+ *   state_dev (B,4) float64, updated in place;  action: action_dev[b * action_stride] (float32 force; the first
+ *   control of rollout b's sequence when action_stride = H*m), clamped to [u_min,u_max] first when has_u_bounds
+ *   (src/mpc_controller.py:203-209 returns clamp(u_seq[0])).
+ * Optional outputs (NULL = skip): state_f32_dev (B,4) = float32 of the new state (what the next solve consumes:
+ * torch.tensor(state, dtype=float32) in scripts/run_cartpole_mpc.py:129); done_step_dev (B) int32, set to the step
+ * index the first time a plant terminates (initialise to -1); log_states_dev (T+1,B,4) float64 and
+ * log_controls_dev (T,B) float32 receive row step+1 / row step.  The step index is *step_dev when step_dev != NULL
+ * (a device counter, so that a captured HIP graph can be replayed), else step_host. */
+int phnn_plant_step(phnn_handle* h, const phnn_plant* plant, double* state_dev, const float* action_dev,
+                    int64_t action_stride, int64_t B, int32_t has_u_bounds, float u_min, float u_max,
+                    float* state_f32_dev, int32_t* done_step_dev, const int32_t* step_dev, int32_t step_host,
+                    double* log_states_dev, float* log_controls_dev, void* stream);
+
+/* Warm start of the next solve, src/mpc_controller_canonical.py:252-255: dst[b,t] = src[b,t+1] for t < H-1,
+ * dst[b,H-1] = 0 (u (B,H,m), shift by one step).  Also advances *step_dev by one when step_dev != NULL. */
+int phnn_shift_controls(phnn_handle* h, const float* src_dev, float* dst_dev, int64_t B, int32_t H, int32_t m,
+                        int32_t* step_dev, void* stream);
+
 /* Introspection for benches/tests: name of the kernel variant selected for this handle, rollouts per
  * workgroup, LDS bytes staged per workgroup. */
 int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts_per_wg,
@@ -167,7 +223,7 @@ int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts
 
 /* Name of the kernel variant serving this handle, e.g. "phnn<n=4,hid=128,fixedG,f16x2>".  The hidden x hidden
  * products run as all-f32 MFMAs ("f32"), as an exact 3-way bf16 split ("bf16x3") or 2-way f16 split ("f16x2",
- * default) on the matrix pipe; the environment variable PHNN_MATMUL selects one at phnn_create time. */
+ * default for 128-wide models) on the matrix pipe; phnn_options.matmul_mode selects one at phnn_create_ex time. */
 const char* phnn_variant_name(const phnn_handle* h);
 
 /* Library version (major*10000 + minor*100 + patch). */

@@ -14,14 +14,18 @@ MODEL_PHNN, MODEL_CANONICAL, MODEL_ODEFUNC = 0, 1, 2
 INTEG_EULER, INTEG_RK4 = 0, 1
 INTEGRATORS = {"euler": INTEG_EULER, "rk4": INTEG_RK4}
 
+ACT_TANH, ACT_OTHER = 0, 1
+MATMUL_MODES = {"default": 0, "f32": 1, "bf16x3": 2, "f16x2": 3}
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libphnn_mpc.so")
+# PHNN_LIB_PATH: load another build of the library (A/B comparisons, tools/ab_bench.sh) without touching the product file
+LIB_PATH = os.environ.get("PHNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libphnn_mpc.so")
 
 # every symbol include/phnn_mpc.h declares
 EXPORTED = [
-    "phnn_create", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
+    "phnn_create", "phnn_create_ex", "phnn_update_weights", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
     "phnn_model_vjp", "phnn_rollout_fwd", "phnn_workspace_bytes", "phnn_rollout_grad", "phnn_rollout_vjp",
-    "phnn_adam_step", "phnn_kernel_info", "phnn_variant_name",
+    "phnn_adam_step", "phnn_plant_step", "phnn_shift_controls", "phnn_kernel_info", "phnn_variant_name",
     "phnn_version",
 ]
 
@@ -43,7 +47,22 @@ class MlpShape(C.Structure):
 
 class Desc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("fixed_G", C.c_int32),
-                ("h_net", MlpShape), ("r_net", MlpShape), ("g_net", MlpShape)]
+                ("h_net", MlpShape), ("r_net", MlpShape), ("g_net", MlpShape), ("activation", C.c_int32)]
+
+
+class Plant(C.Structure):
+    """phnn_plant: the reference's cart-pole constants (src/cartpole_simulator.py:26-36, 107-110)."""
+    _fields_ = [("gravity", C.c_double), ("masscart", C.c_double), ("masspole", C.c_double), ("length", C.c_double),
+                ("dt", C.c_double), ("x_limit", C.c_double), ("theta_limit", C.c_double)]
+
+    @classmethod
+    def default(cls, dt=0.02):
+        return cls(9.8, 1.0, 0.1, 0.5, float(dt), 10.0, 0.5)
+
+
+class Options(C.Structure):
+    _fields_ = [("matmul_mode", C.c_int32), ("force_matmul", C.c_int32), ("max_waves", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class Cost(C.Structure):
@@ -118,6 +137,11 @@ def load_library():
     vp, f32p, i64, i32 = C.c_void_p, C.c_void_p, C.c_int64, C.c_int32
     lib.phnn_create.argtypes = [C.POINTER(Desc), C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(vp)]
     lib.phnn_create.restype = C.c_int
+    lib.phnn_create_ex.argtypes = [C.POINTER(Desc), C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(Options),
+                                   C.POINTER(vp)]
+    lib.phnn_create_ex.restype = C.c_int
+    lib.phnn_update_weights.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, vp]
+    lib.phnn_update_weights.restype = C.c_int
     lib.phnn_destroy.argtypes = [vp]
     lib.phnn_destroy.restype = C.c_int
     lib.phnn_last_error.argtypes = [vp]
@@ -141,6 +165,11 @@ def load_library():
     lib.phnn_adam_step.argtypes = [vp, f32p, f32p, f32p, f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32,
                                    f32p, f32p, f32p, i64, C.c_float, C.c_float, i32, vp]
     lib.phnn_adam_step.restype = C.c_int
+    lib.phnn_plant_step.argtypes = [vp, C.POINTER(Plant), vp, f32p, i64, i64, i32, C.c_float, C.c_float, f32p, vp, vp, i32,
+                                    vp, f32p, vp]
+    lib.phnn_plant_step.restype = C.c_int
+    lib.phnn_shift_controls.argtypes = [vp, f32p, f32p, i64, i32, i32, vp, vp]
+    lib.phnn_shift_controls.restype = C.c_int
     lib.phnn_kernel_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i64]
     lib.phnn_kernel_info.restype = C.c_int
     lib.phnn_variant_name.argtypes = [vp]

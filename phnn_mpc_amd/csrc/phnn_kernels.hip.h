@@ -1526,4 +1526,71 @@ __global__ void k_best_cost(const float* cost, float* best_cost, long long B) {
   long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B && cost[b] < best_cost[b]) best_cost[b] = cost[b];
 }
+
+// Plant: the reference's ground-truth cart-pole (src/cartpole_simulator.py:63-112), float64, one thread per plant.
+// Operation order as in the reference (compiled with -ffp-contract=off: no fused multiply-adds).
+struct PlantParams {
+  phnn_plant pl;
+  double* state;        // (B,4) in/out
+  const float* action;  // action[b * stride]
+  long long stride, B;
+  int has_u_bounds;
+  float u_min, u_max;
+  float* state_f32;
+  int* done_step;
+  const int* step_dev;
+  int step_host;
+  double* log_states;   // (T+1,B,4)
+  float* log_controls;  // (T,B)
+};
+
+__global__ void k_plant_step(PlantParams p) {
+  long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  const int step = p.step_dev ? *p.step_dev : p.step_host;
+  float uf = p.action[b * p.stride];
+  if (p.has_u_bounds) uf = fminf(fmaxf(uf, p.u_min), p.u_max);
+  const double force = (double)uf;
+  const double polemass_length = p.pl.masspole * p.pl.length, total_mass = p.pl.masspole + p.pl.masscart;
+  double x = p.state[4 * b + 0], theta = p.state[4 * b + 1], x_dot = p.state[4 * b + 2], theta_dot = p.state[4 * b + 3];
+  const double costheta = cos(theta), sintheta = sin(theta);
+  const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+  const double thetaacc = (p.pl.gravity * sintheta - costheta * temp) /
+                          (p.pl.length * (4.0 / 3.0 - p.pl.masspole * (costheta * costheta) / total_mass));
+  const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+  x = x + p.pl.dt * x_dot;
+  theta = theta + p.pl.dt * theta_dot;
+  x_dot = x_dot + p.pl.dt * xacc;
+  theta_dot = theta_dot + p.pl.dt * thetaacc;
+  p.state[4 * b + 0] = x;
+  p.state[4 * b + 1] = theta;
+  p.state[4 * b + 2] = x_dot;
+  p.state[4 * b + 3] = theta_dot;
+  if (p.state_f32) {
+    p.state_f32[4 * b + 0] = (float)x;
+    p.state_f32[4 * b + 1] = (float)theta;
+    p.state_f32[4 * b + 2] = (float)x_dot;
+    p.state_f32[4 * b + 3] = (float)theta_dot;
+  }
+  const bool done = fabs(x) > p.pl.x_limit || fabs(theta) > p.pl.theta_limit;
+  if (p.done_step && done && p.done_step[b] < 0) p.done_step[b] = step;
+  if (p.log_states) {
+    double* row = p.log_states + ((long long)(step + 1) * p.B + b) * 4;
+    row[0] = x;
+    row[1] = theta;
+    row[2] = x_dot;
+    row[3] = theta_dot;
+  }
+  if (p.log_controls) p.log_controls[(long long)step * p.B + b] = uf;
+}
+
+// warm start: dst[b,t,:] = src[b,t+1,:], last step zero (src/mpc_controller_canonical.py:252-255); advances the step counter
+__global__ void k_shift_controls(const float* src, float* dst, long long B, int H, int m, int* step_dev) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0 && step_dev) *step_dev += 1;  // k_plant_step of this control step has completed (stream order)
+  const long long per = (long long)H * m;
+  if (idx >= B * per) return;
+  const long long r = idx % per;
+  dst[idx] = r < per - m ? src[idx + m] : 0.0f;
+}
 #endif  // PHNN_ADJOINT_UNIT

@@ -103,23 +103,35 @@ bool same_hidden(const phnn_mlp_shape& s, int depth, int hid) {
   return true;
 }
 
-// How the hidden x hidden products are evaluated where a variant exists: PHNN_MATMUL = f32 | bf16x3 | f16x2
-// (tools/probe_bf16_split.hip).  Default: kDefaultMatmul.
+// How the hidden x hidden products are evaluated where a variant exists (tools/probe_bf16_split.hip).
 // Default: f16x2 for the 128-wide kernels (the products dominate there; cart-pole parity margins 0.1 of the
 // tolerance), all-f32 for the 64-wide ones (little to gain, and the trained pendulum model -- long, large-amplitude
-// swings -- uses 0.9 of the cost tolerance with f32 products already and 1.2 with f16x2 in a 100-step stress case).
-int matmul_mode(int hid = 128) {
+// swings -- uses 0.9 of the cost tolerance with f32 products already and 1.2 with f16x2 in a 100-step stress case:
+// f16x2 is refused there unless phnn_options.force_matmul is set).  The mode comes from phnn_options only.
+int matmul_mode(const phnn_options& o, int hid) {
   const int dflt = hid >= 128 ? MM_F16X2 : MM_F32;
-  const char* e = getenv("PHNN_MATMUL");
-  if (!e) return dflt;
-  if (strcmp(e, "f32") == 0) return MM_F32;
-  if (strcmp(e, "bf16x3") == 0) return MM_BF16X3;
-  if (strcmp(e, "f16x2") == 0) return MM_F16X2;
-  return dflt;
+  switch (o.matmul_mode) {
+    case PHNN_MATMUL_F32: return MM_F32;
+    case PHNN_MATMUL_BF16X3: return MM_BF16X3;
+    case PHNN_MATMUL_F16X2: return MM_F16X2;
+    default: return dflt;
+  }
 }
 
-int pick_variant(const phnn_desc* d, std::string* why) {
+int pick_variant(const phnn_desc* d, const phnn_options& opt, std::string* why) {
   char buf[256];
+  if (d->activation != PHNN_ACT_TANH) {
+    *why = "activation: only Tanh MLPs have kernels (src/NN.py takes any activation; every shipped config selects Tanh)";
+    return V_NONE;
+  }
+  {
+    const int hid0 = d->h_net.hidden[0];
+    if (hid0 < 128 && opt.matmul_mode == PHNN_MATMUL_F16X2 && !opt.force_matmul) {
+      *why = "matmul_mode f16x2 on a model narrower than 128: known to exceed the stated tolerance on the trained "
+             "pendulum model in long rollouts; set phnn_options.force_matmul to run it anyway";
+      return V_NONE;
+    }
+  }
   if (d->m != 1) {
     snprintf(buf, sizeof buf, "input_dim m=%d: the gfx950 kernels are instantiated for m=1 only", d->m);
     *why = buf;
@@ -130,13 +142,17 @@ int pick_variant(const phnn_desc* d, std::string* why) {
     bool ok = same_hidden(d->h_net, 2, hid) && same_hidden(d->r_net, 1, hid) &&
               (d->fixed_G || same_hidden(d->g_net, 1, hid));
     if (ok && d->n == 4 && hid == 128 && d->fixed_G) {
-      int mm = matmul_mode();
+      int mm = matmul_mode(opt, 128);
       return mm == MM_F16X2 ? V_PHNN_4_128_FIX_H : (mm == MM_BF16X3 ? V_PHNN_4_128_FIX_BF : V_PHNN_4_128_FIX);
     }
-    const bool h16 = matmul_mode(hid) == MM_F16X2;
+    const bool h16 = matmul_mode(opt, hid) == MM_F16X2;
     if (ok && d->n == 4 && hid == 64 && d->fixed_G) return h16 ? V_PHNN_4_64_FIX_H : V_PHNN_4_64_FIX;
     if (ok && d->n == 2 && hid == 64 && !d->fixed_G) return h16 ? V_PHNN_2_64_GNET_H : V_PHNN_2_64_GNET;
     if (ok && d->n == 2 && hid == 64 && d->fixed_G) return h16 ? V_PHNN_2_64_FIX_H : V_PHNN_2_64_FIX;
+    if (ok && hid == 128 && matmul_mode(opt, 128) != MM_F16X2 && !(d->n == 4 && d->fixed_G)) {
+      *why = "this (n, G) combination at width 128 has f16x2 kernels only";
+      return V_NONE;
+    }
     if (ok && d->n == 4 && hid == 128 && !d->fixed_G) return V_PHNN_4_128_GNET_H;
     if (ok && d->n == 2 && hid == 128) return d->fixed_G ? V_PHNN_2_128_FIX_H : V_PHNN_2_128_GNET_H;
     snprintf(buf, sizeof buf,
@@ -149,10 +165,10 @@ int pick_variant(const phnn_desc* d, std::string* why) {
   if (d->kind == PHNN_MODEL_CANONICAL) {
     int hid = d->h_net.hidden[0];
     if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 128) {
-      int mm = matmul_mode();
+      int mm = matmul_mode(opt, 128);
       return mm == MM_F16X2 ? V_CANON_128_H : (mm == MM_BF16X3 ? V_CANON_128_BF : V_CANON_128);
     }
-    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 64) return matmul_mode(64) == MM_F16X2 ? V_CANON_64_H : V_CANON_64;
+    if (d->n == 4 && same_hidden(d->h_net, 2, hid) && hid == 64) return matmul_mode(opt, 64) == MM_F16X2 ? V_CANON_64_H : V_CANON_64;
     snprintf(buf, sizeof buf, "canonical pHNN n=%d H_net depth %d width %d: no kernel instantiated", d->n,
              d->h_net.depth, hid);
     *why = buf;
@@ -161,9 +177,9 @@ int pick_variant(const phnn_desc* d, std::string* why) {
   if (d->kind == PHNN_MODEL_ODEFUNC) {
     int hid = d->h_net.hidden[0];
     bool ok = same_hidden(d->h_net, 3, hid);
-    if (ok && d->n == 2 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_2_128_H : V_ODE_2_128;
-    if (ok && d->n == 2 && hid == 64) return matmul_mode(64) == MM_F16X2 ? V_ODE_2_64_H : V_ODE_2_64;
-    if (ok && d->n == 3 && hid == 128) return matmul_mode() == MM_F16X2 ? V_ODE_3_128_H : V_ODE_3_128;
+    if (ok && d->n == 2 && hid == 128) return matmul_mode(opt, 128) == MM_F16X2 ? V_ODE_2_128_H : V_ODE_2_128;
+    if (ok && d->n == 2 && hid == 64) return matmul_mode(opt, 64) == MM_F16X2 ? V_ODE_2_64_H : V_ODE_2_64;
+    if (ok && d->n == 3 && hid == 128) return matmul_mode(opt, 128) == MM_F16X2 ? V_ODE_3_128_H : V_ODE_3_128;
     if (ok && d->n == 4 && hid == 128) return V_ODE_4_128;
     snprintf(buf, sizeof buf, "ODEFunc n=%d depth %d width %d: no kernel instantiated (have n=2,3,4 width 128; n=2 width 64; 3 hidden)",
              d->n, d->h_net.depth, hid);
@@ -544,12 +560,17 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
 }  // namespace
 
 struct phnn_handle {
-  phnn_desc desc;
+  phnn_desc desc;    // as given by the caller
+  phnn_desc pdesc;   // zero-padded to a kernel width
+  phnn_options opt;
   int device;
   int variant;
   KernelSet ks;
   float* d_img;
+  float* h_img;      // pinned staging copy of the image (phnn_update_weights uploads from it asynchronously)
+  size_t img_floats;
   int n_cu;
+  int max_waves;
   std::string err;
 };
 
@@ -567,42 +588,53 @@ int hip_fail(phnn_handle* h, hipError_t e, const char* what) {
 
 // waves per workgroup: as many as 8 (2 per SIMD) once there are enough tiles to give every CU a
 // workgroup; fewer waves per workgroup for small batches so the tiles spread over the CUs.
-int pick_waves(long long tiles, int n_cu) {
-  int w = kMaxWaves;
-  if (const char* e = getenv("PHNN_MAX_WAVES")) {  // diagnostic knob: 4 = one wave per SIMD
-    int v = atoi(e);
-    if (v >= 1 && v <= kMaxWaves) w = v;
-  }
+int pick_waves(long long tiles, int n_cu, int max_waves) {
+  int w = (max_waves >= 1 && max_waves <= kMaxWaves) ? max_waves : kMaxWaves;  // phnn_options.max_waves (4 = one per SIMD)
   while (w > 1 && (tiles + w - 1) / w < n_cu) w >>= 1;
   return w;
 }
 
 template <class P>
 int launch(phnn_handle* h, void (*kern)(P), const P& p, long long tiles, bool grid_stride, hipStream_t st) {
-  int waves = pick_waves(tiles, h->n_cu);
+  int waves = pick_waves(tiles, h->n_cu, h->max_waves);
   long long grid = (tiles + waves - 1) / waves;
   if (grid_stride && grid > 4LL * h->n_cu) grid = 4LL * h->n_cu;
   if (grid < 1) grid = 1;
   size_t shmem = sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * h->ks.scr_floats);
   if (shmem > 160 * 1024) return fail(h, PHNN_ERR_UNSUPPORTED, "weight image does not fit the 160 KiB of LDS");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)shmem);
-  if (e != hipSuccess) return hip_fail(h, e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  // (hipFuncAttributeMaxDynamicSharedMemorySize was raised once per kernel in phnn_create_ex: allow_big_lds)
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), shmem, st, p);
-  e = hipGetLastError();
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
   return PHNN_OK;
 }
 
-int check_device(phnn_handle* h) {
-  int cur = -1;
-  hipError_t e = hipGetDevice(&cur);
-  if (e != hipSuccess) return hip_fail(h, e, "hipGetDevice");
-  if (cur != h->device) {
-    e = hipSetDevice(h->device);
-    if (e != hipSuccess) return hip_fail(h, e, "hipSetDevice");
+// Makes the handle's device current for the duration of one C-ABI call and restores the caller's device after it.
+struct DeviceGuard {
+  int prev = -1, rc = PHNN_OK;
+  bool switched = false;
+  DeviceGuard(phnn_handle* h, int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) { rc = hip_fail(h, e, "hipGetDevice"); return; }
+    if (prev != device) {
+      e = hipSetDevice(device);
+      if (e != hipSuccess) { rc = hip_fail(h, e, "hipSetDevice"); return; }
+      switched = true;
+    }
   }
-  return PHNN_OK;
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+#define PHNN_ON_DEVICE(h)            \
+  DeviceGuard guard_((h), (h)->device); \
+  if (guard_.rc) return guard_.rc
+
+// dynamic LDS above 64 KiB has to be allowed per kernel once; done for every kernel of the set at create time
+template <class P>
+hipError_t allow_big_lds(void (*kern)(P)) {
+  if (!kern) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 int check_cost(phnn_handle* h, const phnn_cost* c) {
@@ -615,7 +647,7 @@ int check_cost(phnn_handle* h, const phnn_cost* c) {
 
 extern "C" {
 
-int phnn_version(void) { return 100; }
+int phnn_version(void) { return 200; }
 
 const char* phnn_variant_name(const phnn_handle* h) { return h ? h->ks.name : ""; }
 
@@ -624,56 +656,127 @@ size_t phnn_weight_count(const phnn_desc* desc) { return weight_count(desc); }
 const char* phnn_last_error(const phnn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int phnn_create(const phnn_desc* desc, const float* weights_host, size_t n_floats, int device, phnn_handle** out) {
-  if (!desc || !weights_host || !out) return fail(nullptr, PHNN_ERR_INVALID_ARG, "NULL argument");
-  *out = nullptr;
+  return phnn_create_ex(desc, weights_host, n_floats, device, nullptr, out);
+}
+
+static int build_image(const phnn_desc* desc, const float* weights_host, size_t n_floats, const phnn_options& opt,
+                       phnn_desc* pdesc, int* variant, std::vector<float>* img, std::string* why, int* code) {
   size_t need = weight_count(desc);
-  if (need == 0) return fail(nullptr, PHNN_ERR_INVALID_ARG, "invalid model description");
+  *code = PHNN_ERR_INVALID_ARG;
+  if (need == 0) { *why = "invalid model description"; return 1; }
   if (need != n_floats) {
     char buf[128];
     snprintf(buf, sizeof buf, "weight blob has %zu floats, description needs %zu", n_floats, need);
-    return fail(nullptr, PHNN_ERR_INVALID_ARG, buf);
+    *why = buf;
+    return 1;
   }
+  *code = PHNN_ERR_UNSUPPORTED;
+  std::vector<float> pblob;
+  if (!pad_model(desc, weights_host, pdesc, &pblob, why)) return 1;
+  int v = pick_variant(pdesc, opt, why);
+  if (v == V_NONE) return 1;
+  *variant = v;
+  pack_image(v, *img, pdesc, pblob.data());
+  *code = PHNN_OK;
+  return 0;
+}
+
+int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_floats, int device,
+                   const phnn_options* opt_in, phnn_handle** out) {
+  if (!desc || !weights_host || !out) return fail(nullptr, PHNN_ERR_INVALID_ARG, "NULL argument");
+  *out = nullptr;
+  phnn_options opt;
+  memset(&opt, 0, sizeof opt);
+  if (opt_in) opt = *opt_in;
+  if (opt.matmul_mode < PHNN_MATMUL_DEFAULT || opt.matmul_mode > PHNN_MATMUL_F16X2 || opt.max_waves < 0 ||
+      opt.max_waves > kMaxWaves)
+    return fail(nullptr, PHNN_ERR_INVALID_ARG, "phnn_options: matmul_mode or max_waves out of range");
   std::string why;
   phnn_desc pdesc;
-  std::vector<float> pblob;
-  if (!pad_model(desc, weights_host, &pdesc, &pblob, &why)) return fail(nullptr, PHNN_ERR_UNSUPPORTED, why);
-  int v = pick_variant(&pdesc, &why);
-  if (v == V_NONE) return fail(nullptr, PHNN_ERR_UNSUPPORTED, why);
+  std::vector<float> img;
+  int v = V_NONE, code = PHNN_OK;
+  if (build_image(desc, weights_host, n_floats, opt, &pdesc, &v, &img, &why, &code)) return fail(nullptr, code, why);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
     return fail(nullptr, PHNN_ERR_HIP, "no HIP device available (the rollout engine has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(nullptr, PHNN_ERR_INVALID_ARG, "device index out of range");
-  e = hipSetDevice(device);
-  if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+  DeviceGuard guard(nullptr, device);
+  if (guard.rc) return guard.rc;
   phnn_handle* h = new phnn_handle();
   h->desc = *desc;
+  h->pdesc = pdesc;
+  h->opt = opt;
   h->device = device;
   h->variant = v;
+  h->max_waves = opt.max_waves > 0 ? opt.max_waves : kMaxWaves;
+  h->d_img = nullptr;
+  h->h_img = nullptr;
   kernel_set(v, &h->ks);
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device);
   h->n_cu = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  std::vector<float> img;
-  pack_image(v, img, &pdesc, pblob.data());
+  h->img_floats = img.size();
+  if (sizeof(float) * (img.size() + (size_t)kMaxWaves * h->ks.scr_floats) > 160 * 1024) {
+    delete h;
+    return fail(nullptr, PHNN_ERR_UNSUPPORTED, "weight image does not fit the 160 KiB of LDS");
+  }
+  e = allow_big_lds(h->ks.fwd[0]);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.fwd[1]);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.fwd_stash);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.grad[0]);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.grad[1]);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.grad_stash);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.mfwd);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.mvjp);
+  if (e != hipSuccess) {
+    delete h;
+    return hip_fail(nullptr, e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  }
   e = hipMalloc(reinterpret_cast<void**>(&h->d_img), sizeof(float) * img.size());
   if (e != hipSuccess) {
     delete h;
     return hip_fail(nullptr, e, "hipMalloc(weights image)");
   }
-  e = hipMemcpy(h->d_img, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice);
+  e = hipHostMalloc(reinterpret_cast<void**>(&h->h_img), sizeof(float) * img.size(), hipHostMallocDefault);
+  if (e == hipSuccess) {
+    memcpy(h->h_img, img.data(), sizeof(float) * img.size());
+    e = hipMemcpy(h->d_img, h->h_img, sizeof(float) * img.size(), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
+    if (h->h_img) (void)hipHostFree(h->h_img);
     (void)hipFree(h->d_img);
     delete h;
-    return hip_fail(nullptr, e, "hipMemcpy(weights image)");
+    return hip_fail(nullptr, e, "upload of the weights image");
   }
   *out = h;
+  return PHNN_OK;
+}
+
+int phnn_update_weights(phnn_handle* h, const float* weights_host, size_t n_floats, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!weights_host) return fail(h, PHNN_ERR_INVALID_ARG, "weights_host is NULL");
+  std::string why;
+  phnn_desc pdesc;
+  std::vector<float> img;
+  int v = V_NONE, code = PHNN_OK;
+  if (build_image(&h->desc, weights_host, n_floats, h->opt, &pdesc, &v, &img, &why, &code)) return fail(h, code, why);
+  if (v != h->variant || img.size() != h->img_floats) return fail(h, PHNN_ERR_INVALID_ARG, "weights select another kernel variant");
+  PHNN_ON_DEVICE(h);
+  hipStream_t st = (hipStream_t)stream;
+  // the pinned staging buffer may still feed the previous asynchronous upload: wait for this stream first
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hip_fail(h, e, "hipStreamSynchronize");
+  memcpy(h->h_img, img.data(), sizeof(float) * img.size());
+  e = hipMemcpyAsync(h->d_img, h->h_img, sizeof(float) * img.size(), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return hip_fail(h, e, "hipMemcpyAsync(weights image)");
   return PHNN_OK;
 }
 
 int phnn_destroy(phnn_handle* h) {
   if (!h) return PHNN_OK;
   if (h->d_img) (void)hipFree(h->d_img);
+  if (h->h_img) (void)hipHostFree(h->h_img);
   delete h;
   return PHNN_OK;
 }
@@ -683,7 +786,7 @@ int phnn_model_forward(phnn_handle* h, const float* x_dev, const float* u_dev, i
   if (!h) return PHNN_ERR_INVALID_ARG;
   if (B == 0) return PHNN_OK;
   if (!x_dev || !u_dev || !dx_dev || B < 0) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
-  if (int rc = check_device(h)) return rc;
+  PHNN_ON_DEVICE(h);
   PointParams p{h->d_img, x_dev, u_dev, nullptr, dx_dev, H_dev, (long long)B};
   return launch(h, h->ks.mfwd, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
 }
@@ -694,7 +797,7 @@ int phnn_model_vjp(phnn_handle* h, const float* x_dev, const float* u_dev, const
   if (B == 0) return PHNN_OK;
   if (!x_dev || !u_dev || !lam_dev || !xbar_dev || !ubar_dev || B < 0)
     return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
-  if (int rc = check_device(h)) return rc;
+  PHNN_ON_DEVICE(h);
   PointParams p{h->d_img, x_dev, u_dev, lam_dev, xbar_dev, ubar_dev, (long long)B};
   return launch(h, h->ks.mvjp, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
 }
@@ -735,7 +838,7 @@ int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
   if (B == 0) return PHNN_OK;
   if (!cost_dev) return fail(h, PHNN_ERR_INVALID_ARG, "cost_dev is NULL");
-  if (int rc = check_device(h)) return rc;
+  PHNN_ON_DEVICE(h);
   p.cost = cost_dev;
   p.traj = traj_dev;
   const bool stash = workspace_dev && integrator == PHNN_INTEG_EULER;
@@ -760,7 +863,7 @@ int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
   if (B == 0) return PHNN_OK;
   if (!traj_dev || !grad_u_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev / grad_u_dev is NULL");
-  if (int rc = check_device(h)) return rc;
+  PHNN_ON_DEVICE(h);
   p.traj_in = traj_dev;
   p.traj_bar = traj_bar_dev;
   p.cost_bar = cost_bar_dev;
@@ -782,7 +885,7 @@ int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* e
   if (best_cost_dev && (!cost_dev || !best_u_dev || per < 1 || count % per != 0))
     return fail(h, PHNN_ERR_INVALID_ARG, "best-iterate tracking needs cost_dev, best_u_dev and per | count");
   if (count == 0) return PHNN_OK;
-  if (int rc = check_device(h)) return rc;
+  PHNN_ON_DEVICE(h);
   AdamParams p;
   memset(&p, 0, sizeof p);
   p.u = u_dev;
@@ -819,12 +922,65 @@ int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* e
   return PHNN_OK;
 }
 
+int phnn_plant_step(phnn_handle* h, const phnn_plant* plant, double* state_dev, const float* action_dev,
+                    int64_t action_stride, int64_t B, int32_t has_u_bounds, float u_min, float u_max,
+                    float* state_f32_dev, int32_t* done_step_dev, const int32_t* step_dev, int32_t step_host,
+                    double* log_states_dev, float* log_controls_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (B == 0) return PHNN_OK;
+  if (!plant || !state_dev || !action_dev || B < 0 || action_stride < 0)
+    return fail(h, PHNN_ERR_INVALID_ARG, "NULL plant / state / action, or negative batch / stride");
+  if (has_u_bounds && !(u_min <= u_max)) return fail(h, PHNN_ERR_INVALID_ARG, "u_min > u_max");
+  if ((log_states_dev || log_controls_dev) && !step_dev && step_host < 0)
+    return fail(h, PHNN_ERR_INVALID_ARG, "negative step index");
+  PHNN_ON_DEVICE(h);
+  PlantParams p;
+  memset(&p, 0, sizeof p);
+  p.pl = *plant;
+  p.state = state_dev;
+  p.action = action_dev;
+  p.stride = action_stride;
+  p.B = B;
+  p.has_u_bounds = has_u_bounds;
+  p.u_min = u_min;
+  p.u_max = u_max;
+  p.state_f32 = state_f32_dev;
+  p.done_step = done_step_dev;
+  p.step_dev = step_dev;
+  p.step_host = step_host;
+  p.log_states = log_states_dev;
+  p.log_controls = log_controls_dev;
+  const int threads = 256;
+  hipLaunchKernelGGL(k_plant_step, dim3((unsigned)((B + threads - 1) / threads)), dim3(threads), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "plant step launch");
+  return PHNN_OK;
+}
+
+int phnn_shift_controls(phnn_handle* h, const float* src_dev, float* dst_dev, int64_t B, int32_t H, int32_t m,
+                        int32_t* step_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (B < 0 || H < 1 || m < 1) return fail(h, PHNN_ERR_INVALID_ARG, "negative batch, H < 1 or m < 1");
+  if (B > 0 && (!src_dev || !dst_dev || src_dev == dst_dev))
+    return fail(h, PHNN_ERR_INVALID_ARG, "NULL or aliased control tensors");
+  if (B == 0 && !step_dev) return PHNN_OK;  // B == 0 with a counter: only advance the step
+  PHNN_ON_DEVICE(h);
+  const int threads = 256;
+  long long count = (long long)B * H * m;
+  if (count < 1) count = 1;
+  hipLaunchKernelGGL(k_shift_controls, dim3((unsigned)((count + threads - 1) / threads)), dim3(threads), 0,
+                     (hipStream_t)stream, src_dev, dst_dev, (long long)B, (int)H, (int)m, step_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "shift launch");
+  return PHNN_OK;
+}
+
 int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts_per_wg, int32_t* lds_bytes,
                      int32_t* n_workgroups_for_B, int64_t B) {
   if (!h) return PHNN_ERR_INVALID_ARG;
   (void)integrator;
   long long tiles = (B + kTileB - 1) / kTileB;
-  int waves = pick_waves(tiles, h->n_cu);
+  int waves = pick_waves(tiles, h->n_cu, h->max_waves);
   if (rollouts_per_wg) *rollouts_per_wg = waves * kTileB;
   if (lds_bytes) *lds_bytes = (int32_t)(sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * h->ks.scr_floats));
   if (n_workgroups_for_B) *n_workgroups_for_B = (int32_t)((tiles + waves - 1) / waves);

@@ -31,15 +31,31 @@ class RolloutEngine:
     state_dict: the reference's state_dict (torch tensors or numpy arrays), or a checkpoint wrapping it.
     """
 
-    def __init__(self, state_dict, device="cuda:0", kind=None):
+    def __init__(self, state_dict, device="cuda:0", kind=None, activation="tanh", matmul=None, force_matmul=False,
+                 max_waves=None):
+        """matmul: 'default' | 'f32' | 'bf16x3' | 'f16x2' (None: the PHNN_MATMUL environment variable, else
+        'default').  The environment is read HERE, on the Python side, as a default only; the C-ABI takes the
+        explicit phnn_options.  f16x2 on a model narrower than 128 needs force_matmul=True (known to exceed the
+        stated tolerance there).  max_waves (None: PHNN_MAX_WAVES, else 8): waves per workgroup cap."""
         self.lib = _capi.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise PhnnError("RolloutEngine needs a GPU device (cuda:N); there is no CPU path")
         if not torch.cuda.is_available():
             raise PhnnError("no GPU visible to torch; the rollout engine has no CPU fallback")
-        self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind)
+        self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind, activation=activation)
         self.n, self.m, self.kind = self.desc.n, self.desc.m, self.desc.kind
+        if matmul is None:
+            matmul = os.environ.get("PHNN_MATMUL", "default")
+            force_matmul = force_matmul or "PHNN_MATMUL" in os.environ  # an explicit environment override is a force
+        if matmul not in _capi.MATMUL_MODES:
+            raise ValueError(f"matmul must be one of {sorted(_capi.MATMUL_MODES)}, got {matmul!r}")
+        if max_waves is None:
+            max_waves = int(os.environ.get("PHNN_MAX_WAVES", "0"))
+        self.options = _capi.Options()
+        self.options.matmul_mode = _capi.MATMUL_MODES[matmul]
+        self.options.force_matmul = int(bool(force_matmul))
+        self.options.max_waves = int(max_waves)
         # K1 -> K2 activation stash (Euler): on unless PHNN_NO_STASH=1; capped so a huge batch falls back to
         # the recompute kernels instead of allocating more than max_stash_bytes of HBM
         self.use_stash = os.environ.get("PHNN_NO_STASH", "0") != "1"
@@ -47,10 +63,19 @@ class RolloutEngine:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
         h = C.c_void_p()
-        rc = self.lib.phnn_create(C.byref(self.desc), self.blob.ctypes.data_as(C.POINTER(C.c_float)), self.blob.size,
-                                  idx, C.byref(h))
+        rc = self.lib.phnn_create_ex(C.byref(self.desc), self.blob.ctypes.data_as(C.POINTER(C.c_float)),
+                                     self.blob.size, idx, C.byref(self.options), C.byref(h))
         _check(self.lib, None, rc)
         self.h = h
+
+    def update_weights(self, state_dict):
+        """Re-pack and re-upload the weights of the same architecture (after an optimizer step / load_state_dict)."""
+        desc, blob = weights.pack_state_dict(state_dict, kind=self.kind, activation="tanh")
+        if blob.size != self.blob.size:
+            raise PhnnError("update_weights: the state_dict describes another architecture")
+        self.blob = blob
+        rc = self.lib.phnn_update_weights(self.h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, self._stream())
+        _check(self.lib, self.h, rc)
 
     def close(self):
         if getattr(self, "h", None):
@@ -196,6 +221,31 @@ class RolloutEngine:
                                      self._p(cost), self._p(best_cost), self._p(best_u), per,
                                      float(u_min) if has_b else 0.0, float(u_max) if has_b else 0.0, int(has_b),
                                      self._stream())
+        _check(self.lib, self.h, rc)
+
+    # ------------------------------------------------------------------ the plant, on the device
+    def plant_step(self, plant, state, action, action_stride, u_min=None, u_max=None, state_f32=None, done_step=None,
+                   step=0, step_dev=None, log_states=None, log_controls=None):
+        """One float64 Euler step of the reference cart-pole for B plants, in place on `state` (B,4) float64.
+        action: float32 tensor, plant b takes action.view(-1)[b * action_stride].  See include/phnn_mpc.h."""
+        assert state.dtype == torch.float64 and state.is_contiguous() and state.device == self.device
+        assert action.dtype == torch.float32 and action.is_contiguous() and action.device == self.device
+        B = state.shape[0]
+        has_b = u_min is not None and u_max is not None
+        rc = self.lib.phnn_plant_step(self.h, C.byref(plant), self._p(state), self._p(action), int(action_stride), B,
+                                      int(has_b), float(u_min) if has_b else 0.0, float(u_max) if has_b else 0.0,
+                                      self._p(state_f32), self._p(done_step), self._p(step_dev), int(step),
+                                      self._p(log_states), self._p(log_controls), self._stream())
+        _check(self.lib, self.h, rc)
+
+    def shift_controls(self, src, dst, step_dev=None):
+        """dst[b,t] = src[b,t+1], dst[b,H-1] = 0 (warm start of the next solve); advances *step_dev if given."""
+        B, H, m = src.shape
+        rc = self.lib.phnn_shift_controls(self.h, self._p(src), self._p(dst), B, H, m, self._p(step_dev), self._stream())
+        _check(self.lib, self.h, rc)
+
+    def advance_step(self, step_dev):
+        rc = self.lib.phnn_shift_controls(self.h, None, None, 0, 1, 1, self._p(step_dev), self._stream())
         _check(self.lib, self.h, rc)
 
     @property

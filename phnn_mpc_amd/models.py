@@ -86,17 +86,38 @@ class _EngineBacked(nn.Module):
         self._engine = None
         self._engine_device = DEFAULT_DEVICE
 
+    def _fingerprint(self):
+        """Cheap identity of the current parameter values: (storage pointer, in-place version counter) of every
+        parameter and buffer.  An optimizer step, copy_(), an in-place edit or a re-assigned .data changes it."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
     @property
     def engine(self):
+        """The engine holding the packed weights.  Built lazily; when a parameter has changed since the weights were
+        packed (optimizer step, in-place edit) they are re-packed and re-uploaded before the engine is handed out, so
+        forward/rollouts never run stale weights."""
         if self._engine is None:
             self._check_supported()
             from .engine import RolloutEngine
-            self._engine = RolloutEngine(self.state_dict(), self._engine_device)
+            self._engine = RolloutEngine(self.state_dict(), self._engine_device, activation=self._activation_name())
+            self._packed_fp = self._fingerprint()
+        elif self._packed_fp is not None:
+            fp = self._fingerprint()
+            if fp != self._packed_fp:
+                self._engine.update_weights(self.state_dict())
+                self._packed_fp = fp
         return self._engine
+
+    def _activation_name(self):
+        for mod in self.modules():
+            if isinstance(mod, MLP):
+                return mod.activation_name
+        return "tanh"
 
     def set_engine(self, engine):
         """Attach an already built engine (tests use this to run the host logic without a GPU)."""
         self._engine = engine
+        self._packed_fp = None  # externally managed: no automatic re-packing
         return self
 
     def refresh_engine(self):

@@ -60,13 +60,25 @@ def detect_kind(sd):
     raise ValueError("state_dict is neither a pHNN, a pHNN_Canonical nor an ODEFunc")
 
 
-def pack_state_dict(sd, kind=None, state_dim=None, input_dim=None):
-    """Return (Desc, blob) for a reference state_dict (numpy arrays or torch tensors)."""
+def _activation_code(activation):
+    """'tanh' / 'Tanh' / 'nn.Tanh' / torch.nn.Tanh -> PHNN_ACT_TANH; anything else -> PHNN_ACT_OTHER (refused by
+    phnn_create).  The state_dict itself does not say which activation a checkpoint was trained with."""
+    name = activation if isinstance(activation, str) else getattr(activation, "__name__", str(activation))
+    return _capi.ACT_TANH if name.split(".")[-1].lower() == "tanh" else _capi.ACT_OTHER
+
+
+def pack_state_dict(sd, kind=None, state_dim=None, input_dim=None, activation="tanh"):
+    """Return (Desc, blob) for a reference state_dict (numpy arrays or torch tensors).
+
+    activation: the activation of the MLPs the weights were trained with (the reference resolves it from the YAML,
+    src/pHNN.py:41).  Only Tanh has kernels; any other value makes phnn_create fail instead of silently running a
+    SiLU/ReLU checkpoint -- same keys, same shapes -- as a Tanh network."""
     sd = unwrap_checkpoint(sd)
     if kind is None:
         kind = detect_kind(sd)
     d = _capi.Desc()
     d.kind = kind
+    d.activation = _activation_code(activation)
     parts = []
     if kind == _capi.MODEL_PHNN:
         J = _np(sd["J"])

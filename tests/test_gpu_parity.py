@@ -144,9 +144,9 @@ def test_dataset_windows(torch_cuda):
     for nm, wn in (("phnn", "phnn_cartpole"), ("canonical", "canonical_cartpole")):
         eng = RolloutEngine(ol.load_weights(wn))
         c, gu = eng.rollout_cost_grad(win["x0"], win["U"], ol.cost_from_golden(gc), "euler", 0.02)
-        assert np.allclose(npy(c), win[f"{nm}_cost_f64"], rtol=2e-5)
+        assert np.allclose(npy(c), win[f"{nm}_cost_f64"], rtol=1e-5), np.abs(npy(c) / win[f"{nm}_cost_f64"] - 1).max()
         gmax = np.abs(win[f"{nm}_gu_f64"]).max(axis=(1, 2), keepdims=True)
-        assert np.all(np.abs(npy(gu) - win[f"{nm}_gu_f64"]) <= 2e-4 * gmax)
+        assert np.all(np.abs(npy(gu) - win[f"{nm}_gu_f64"]) <= 1e-4 * gmax), (np.abs(npy(gu) - win[f"{nm}_gu_f64"]) / gmax).max()
 
 
 def test_repeatable_and_shard_equivalent(bundle):
@@ -212,10 +212,9 @@ def test_stash_and_recompute_modes_agree(bundle):
 
 @pytest.mark.parametrize("name", ["phnn_cartpole", "canonical_cartpole"])
 def test_matmul_variants(torch_cuda, name):
-    """The 128x128 products run as an exact 2-way f16 split on the matrix pipe by default (PHNN_MATMUL=f16x2);
+    """The 128x128 products run as an exact 2-way f16 split on the matrix pipe by default (matmul="f16x2");
     bf16x3 is the 3-way bf16 split, f32 the all-f32-MFMA kernels.  Each must sit within the stated tolerances of
-    the float64 oracle."""
-    import os
+    the float64 oracle.  The mode is an explicit phnn_options field (phnn_create_ex), not hidden global state."""
     from phnn_mpc_amd.engine import RolloutEngine
     g, w = ol.load_golden(name), ol.load_weights(name)
     m64 = ol.OracleModel(w, "f64")
@@ -227,11 +226,8 @@ def test_matmul_variants(torch_cuda, name):
     ref = m64.rollout(x0, U, cost, "euler", 0.02, nthreads=8)
     res = {}
     for mode in ("f16x2", "bf16x3", "f32"):
-        os.environ["PHNN_MATMUL"] = mode
-        try:
-            eng = RolloutEngine(w)
-        finally:
-            os.environ.pop("PHNN_MATMUL", None)
+        eng = RolloutEngine(w, matmul=mode)
+        assert eng.matmul_mode == mode
         c, gu, gx = eng.rollout_cost_grad(x0, U, cost, "euler", 0.02, want_grad_x0=True)
         _, tr = eng.rollout_cost(x0, U, cost, "euler", 0.02, want_traj=True)
         assert_rollout_close(npy(c), npy(tr), npy(gu), npy(gx), ref["cost"], ref["traj"], ref["grad_u"], ref["grad_x0"])
@@ -317,17 +313,17 @@ def test_other_phnn_shapes_vs_oracle(torch_cuda, shape):
 
 
 def test_default_matmul_mode_by_width(torch_cuda):
-    """128-wide models default to the f16x2 products, 64-wide ones to all-f32 (PHNN_MATMUL overrides either)."""
+    """128-wide models default to the f16x2 products, 64-wide ones to all-f32.  f16x2 on a 64-wide model is known to
+    exceed the stated tolerance in long rollouts of the trained pendulum model: phnn_create_ex refuses it unless the
+    caller forces it."""
     import os
-    from phnn_mpc_amd.engine import RolloutEngine
+    from phnn_mpc_amd.engine import PhnnError, RolloutEngine
     assert "PHNN_MATMUL" not in os.environ
     assert RolloutEngine(ol.load_weights("phnn_cartpole")).matmul_mode == "f16x2"
     assert RolloutEngine(ol.load_weights("phnn_pendulum")).matmul_mode == "f32"
-    os.environ["PHNN_MATMUL"] = "f16x2"
-    try:
-        eng = RolloutEngine(ol.load_weights("phnn_pendulum"))
-    finally:
-        os.environ.pop("PHNN_MATMUL", None)
+    with pytest.raises(PhnnError, match="force_matmul"):
+        RolloutEngine(ol.load_weights("phnn_pendulum"), matmul="f16x2")
+    eng = RolloutEngine(ol.load_weights("phnn_pendulum"), matmul="f16x2", force_matmul=True)
     assert eng.matmul_mode == "f16x2"
     g = ol.load_golden("phnn_pendulum")
     dx, H = eng.forward(g["fwd_x"], g["fwd_u"])

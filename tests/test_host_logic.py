@@ -41,9 +41,34 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header():
-    # phnn_desc: 4 ints + 3 * (1 + 4) ints ; phnn_cost: 64+16+8 floats, 2 floats, int, 16 floats, 2 ints, float
-    assert C.sizeof(_capi.Desc) == 4 * (4 + 3 * 5)
+    # phnn_desc: 4 ints + 3 * (1 + 4) ints + activation ; phnn_cost: 64+16+8 floats, 2 floats, int, 16 floats, 2 ints,
+    # float ; phnn_options: 3 ints + 5 reserved ; phnn_plant: 7 doubles
+    assert C.sizeof(_capi.Desc) == 4 * (4 + 3 * 5 + 1)
     assert C.sizeof(_capi.Cost) == 4 * (64 + 16 + 8 + 2 + 1 + 16 + 2 + 1)
+    assert C.sizeof(_capi.Options) == 4 * 8
+    assert C.sizeof(_capi.Plant) == 8 * 7
+
+
+def test_activation_is_part_of_the_description():
+    """A checkpoint trained with another activation has the same keys and shapes: the description carries the
+    activation explicitly and everything but Tanh is refused (before any device is touched)."""
+    lib = _capi.load_library()
+    d, blob = weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="nn.SiLU")
+    assert d.activation == _capi.ACT_OTHER
+    h = C.c_void_p()
+    rc = lib.phnn_create_ex(C.byref(d), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, 0, None, C.byref(h))
+    assert rc == -2 and b"Tanh" in lib.phnn_last_error(None)
+    d2, _ = weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="nn.Tanh")
+    assert d2.activation == _capi.ACT_TANH
+    # f16x2 on a 64-wide model is refused unless forced (known to miss the tolerance on the trained pendulum model)
+    d3, blob3 = weights.pack_state_dict(ol.load_weights("phnn_pendulum"))
+    opt = _capi.Options()
+    opt.matmul_mode = _capi.MATMUL_MODES["f16x2"]
+    rc = lib.phnn_create_ex(C.byref(d3), blob3.ctypes.data_as(C.POINTER(C.c_float)), blob3.size, 0, C.byref(opt), C.byref(h))
+    assert rc == -2 and b"force_matmul" in lib.phnn_last_error(None)
+    opt.max_waves = 99
+    rc = lib.phnn_create_ex(C.byref(d3), blob3.ctypes.data_as(C.POINTER(C.c_float)), blob3.size, 0, C.byref(opt), C.byref(h))
+    assert rc == -1
 
 
 @pytest.mark.parametrize("name", ol.MODELS)

@@ -126,3 +126,22 @@ def test_rollout_vjp_with_trajectory_and_cost_cotangents_g10(bundle, integ):
                              traj_bar=g["tvjp_traj_bar"], cost_bar=g["tvjp_cost_bar"])
     assert rel(gu, g[f"tvjp_{integ}_gu_f64"]) < 1e-9
     assert rel(gx, g[f"tvjp_{integ}_gx0_f64"]) < 1e-9
+
+
+def test_torch_restatement_matches_golden():
+    """oracle/torch_oracle.py (the stock PyTorch-CPU restatement timed as bench.py's second CPU baseline) against the
+    reference's own float64 rollouts (G4, Euler cases)."""
+    import sys
+    import torch
+    sys.path.insert(0, ol.ORACLE_DIR)
+    from torch_oracle import TorchPhnn
+    g, w = ol.load_golden("phnn_cartpole"), ol.load_weights("phnn_cartpole")
+    m = TorchPhnn(w, torch.float64)
+    for B, H in ((8, 50), (4, 100)):
+        key = f"roll_euler_B{B}_H{H}"
+        c, gu = m.rollout_cost_grad(g[key + "_x0"], g[key + "_U"], np.diag(g["Q"]) if g["Q"].ndim == 2 else g["Q"],
+                                    float(np.asarray(g["R"]).reshape(-1)[0]), g["x_target"], float(g["u_min"]),
+                                    float(g["u_max"]), float(g["dt"]))
+        # summation order of the cost differs from the reference's Python loops: 1e-9, not bitwise
+        assert np.allclose(c.numpy(), g[key + "_cost_f64"], rtol=1e-8)
+        assert np.allclose(gu.numpy(), g[key + "_gu_f64"], rtol=1e-6, atol=1e-8 * np.abs(g[key + "_gu_f64"]).max())
