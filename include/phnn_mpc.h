@@ -178,6 +178,42 @@ int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, in
                      const void* workspace_dev, const float* traj_bar_dev, const float* cost_bar_dev,
                      float* grad_u_dev, float* grad_x0_dev, void* stream);
 
+/* ---- training side: rollouts with gradients w.r.t. the MODEL PARAMETERS ----------------------
+ * What loss.backward() does in the reference's training loops (scripts/train_cartpole_phnn.py:112-178,
+ * scripts/train_cartpole_phnn_canonical.py:83-196, main.py:93-148): an Euler (or RK4) rollout from x_batch[:,0] with
+ * the dataset's controls, a loss built on the predicted states X_pred and/or the per-step derivatives dX_pred, and the
+ * gradient of that loss w.r.t. every parameter.  The loss itself stays with the caller (torch): these entry points take
+ * its cotangents on the two outputs and return the parameter gradient as a blob laid out exactly like the weight blob
+ * of phnn_create (buffers of the reference modules -- G_fixed, the canonical G -- and the CartPoleMassMatrix
+ * parameters, which are constants to autograd through .item(), src/mass_matrix.py:299-301, stay zero).
+ * Available for PHNN and CANONICAL handles (PHNN_ERR_UNSUPPORTED for ODEFUNC). */
+
+/* Forward of a training rollout: no clamp, no cost.  -> traj_dev (B,H+1,n) = X_pred, dx_dev (B,H,n) = dX_pred
+ * (f(x_t,u_t) at the first stage of each step; may be NULL). */
+int phnn_rollout_trajectory(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                            int32_t integrator, float dt, float* traj_dev, float* dx_dev, void* stream);
+
+/* Bytes of workspace phnn_rollout_wgrad (H >= 1) / phnn_model_wgrad (H = 0, B = number of points) need. */
+size_t phnn_wgrad_workspace_bytes(const phnn_handle* h, int64_t B, int32_t H, int32_t integrator);
+
+/* Reverse pass of the training rollout.  traj_dev: the states phnn_rollout_trajectory wrote; traj_bar_dev (B,H+1,n) and
+ * dx_bar_dev (B,H,n): cotangents of the loss on X_pred and dX_pred (either may be NULL = 0).
+ * -> grad_theta_dev (phnn_weight_count floats; overwritten, or added to when accumulate != 0), grad_u_dev (B,H,m) and
+ * grad_x0_dev (B,n) (both may be NULL).  Two kernels: the adjoint march, which also streams one record per
+ * (16-rollout tile, step, stage) to the workspace, and a reduction of the records into the gradient (GEMMs over the
+ * evaluation points; fixed summation order, bitwise reproducible). */
+int phnn_rollout_wgrad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H, int32_t integrator,
+                       float dt, const float* traj_dev, const float* traj_bar_dev, const float* dx_bar_dev,
+                       void* workspace_dev, float* grad_theta_dev, int32_t accumulate, float* grad_u_dev,
+                       float* grad_x0_dev, void* stream);
+
+/* Single evaluations: gradient of sum_p lam_p . f(x_p,u_p) + Hbar_p H(x_p) w.r.t. the parameters (what backward() does
+ * for model(x,u) calls outside a rollout, e.g. the energy anchor H(0)^2 of scripts/train_cartpole_phnn.py:166-170),
+ * plus xbar_dev (N,n) and ubar_dev (N,m) as phnn_model_vjp (with Hbar dH/dx added).  Hbar_dev (N) may be NULL. */
+int phnn_model_wgrad(phnn_handle* h, const float* x_dev, const float* u_dev, const float* lam_dev, const float* Hbar_dev,
+                     int64_t N, void* workspace_dev, float* grad_theta_dev, int32_t accumulate, float* xbar_dev,
+                     float* ubar_dev, void* stream);
+
 /* K3 -- Adam step on the controls, arithmetic order of torch.optim.Adam (single-tensor, defaults:
  * no weight decay / amsgrad) as used by src/mpc_controller.py:168,200 and
  * src/mpc_controller_canonical.py:186,206.  `step` is the 1-based step count after the increment.

@@ -25,6 +25,7 @@ LIB_PATH = os.environ.get("PHNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libph
 EXPORTED = [
     "phnn_create", "phnn_create_ex", "phnn_update_weights", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
     "phnn_model_vjp", "phnn_rollout_fwd", "phnn_workspace_bytes", "phnn_rollout_grad", "phnn_rollout_vjp",
+    "phnn_rollout_trajectory", "phnn_wgrad_workspace_bytes", "phnn_rollout_wgrad", "phnn_model_wgrad",
     "phnn_adam_step", "phnn_plant_step", "phnn_shift_controls", "phnn_kernel_info", "phnn_variant_name",
     "phnn_version",
 ]
@@ -162,6 +163,15 @@ def load_library():
     lib.phnn_rollout_vjp.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, f32p, vp, f32p, f32p,
                                      f32p, f32p, vp]
     lib.phnn_rollout_vjp.restype = C.c_int
+    lib.phnn_rollout_trajectory.argtypes = [vp, f32p, f32p, i64, i32, i32, C.c_float, f32p, f32p, vp]
+    lib.phnn_rollout_trajectory.restype = C.c_int
+    lib.phnn_wgrad_workspace_bytes.argtypes = [vp, i64, i32, i32]
+    lib.phnn_wgrad_workspace_bytes.restype = C.c_size_t
+    lib.phnn_rollout_wgrad.argtypes = [vp, f32p, f32p, i64, i32, i32, C.c_float, f32p, f32p, f32p, vp, f32p, i32, f32p,
+                                       f32p, vp]
+    lib.phnn_rollout_wgrad.restype = C.c_int
+    lib.phnn_model_wgrad.argtypes = [vp, f32p, f32p, f32p, f32p, i64, vp, f32p, i32, f32p, f32p, vp]
+    lib.phnn_model_wgrad.restype = C.c_int
     lib.phnn_adam_step.argtypes = [vp, f32p, f32p, f32p, f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32,
                                    f32p, f32p, f32p, i64, C.c_float, C.c_float, i32, vp]
     lib.phnn_adam_step.restype = C.c_int

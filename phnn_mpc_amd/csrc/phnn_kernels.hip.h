@@ -380,6 +380,9 @@ DEV f32x4 mfma_h(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_1
 // x - (float)h for a packed pair, one v_fma_mix_f32 each (f16 operand read straight from the packed register:
 // replaces v_cvt_f32_f16 + v_sub_f32; the compiler does not form it from the plain expression)
 DEV f32x2 residual_h(f16x2 h, f32x2 x) {
+#ifdef PHNN_NO_FMAMIX
+  return x - __builtin_convertvector(h, f32x2);
+#endif
   unsigned hb = __builtin_bit_cast(unsigned, h);
   f32x2 r;
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hb), "v"(x[0]));
@@ -534,7 +537,13 @@ DEV void store_act(float* dst, Lane ln, const Act<T>& a) {
 template <int T>
 DEV void load_act(const float* src, Lane ln, Act<T>& a) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) a.v[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + t * 64 + ln.lane);
+  for (int t = 0; t < T; ++t) {
+#ifdef PHNN_PLAIN_STASH_LOADS
+    a.v[t] = reinterpret_cast<const f32x4*>(src)[t * 64 + ln.lane];
+#else
+    a.v[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + t * 64 + ln.lane);
+#endif
+  }
 }
 
 // 16 per-rollout values spread over the 4 lanes of a rollout (lane (i,q) holds values 4q..4q+3) ->
@@ -577,7 +586,7 @@ struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int oW3B = oW3 + HID;         // [HID]   w3 * Sb (g2 = w3 (1 - a2^2), fed to the transposed product)
   static constexpr int oW3S = oW3B + HID;        // [HID]   w3 * Sb / S (used by the Hessian-vector product)
   static constexpr int oW1T = oW3S + HID;        // [4][LR] rows c = W1[:,c] / (S Sb)
-  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 1 / k1, 0), k1 = factor folded into W1, b1
+  static constexpr int oB3 = oW1T + 4 * LR;      // [4] (b3, 2 log2(e) / S, 1 / k1, Sb), k1 = factor folded into W1, b1
   static constexpr int SIZE = oB3 + 4;
 };
 
@@ -598,6 +607,41 @@ struct LayH1 {  // in(<=4) -> HID -> out(<=16)  (R_net, G_net)
   static constexpr int oV1T = oSc + 4;          // [4][LR]
   static constexpr int SIZE = oV1T + 4 * LR;
 };
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient record (training side).  The parameter gradient of lam^T f(x,u;theta) needs, per
+// evaluation point, the tapes the VJP already holds in registers.  The adjoint kernels (template flag WG) stream them
+// to HBM as one record per (16-point tile, evaluation); k_wgrad_reduce turns records into gradient sums as GEMMs over
+// the points.  Record of a model with hidden width 16 T, in floats:
+//   [v * T*256, (v+1) * T*256)   big vector v in accumulator layout ([tile t][lane] float4, one coalesced 1 KB store per tile):
+//        0 a2            second hidden activation of H_net
+//        1 q1 raw        W2^T g2 as the kernel holds it   (= S Sb q1)
+//        2 ad2 raw       (1 - a2^2) W2 adot1, un-normalised (= S k1 adot2)
+//        3 qd raw        W2^T of the -gdot2/2 the kernel forms, un-normalised (= -S Sb k1 qd / 2)
+//        4 hbR           R_net: (V2^T rbar) (1 - h^2)      (pHNN only)
+//        5 hbG           G_net: (V2^T gbar) (1 - h^2)      (learned G only)
+//   then 16 rollouts x kRecSmall floats: x[4] (H_net input), v[4], lam[4], dH[4], rbar[16], u, Hbar, pad[2]
+// (S, Sb, k1: power-of-two / tanh-constant scales folded into the image, LayH2::oB3.)
+// ------------------------------------------------------------------------------------------------
+constexpr int kRecSmall = 36;
+template <int T, int NBIG>
+struct WRec {
+  static constexpr int VEC = T * 256;
+  static constexpr int oSmall = NBIG * VEC;
+  static constexpr int SIZE = oSmall + 16 * kRecSmall;
+};
+
+// plain (cached) store: the reduce kernel reads the record back soon, possibly from the Infinity Cache
+template <int T>
+DEV void store_rec(float* dst, Lane ln, const Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) reinterpret_cast<f32x4*>(dst)[t * 64 + ln.lane] = a.v[t];
+}
+template <int T>
+DEV void store_rec_scaled(float* dst, Lane ln, const Act<T>& a, float s) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) reinterpret_cast<f32x4*>(dst)[t * 64 + ln.lane] = a.v[t] * s;
+}
 
 // ------------------------------------------------------------------------------------------------
 // H_net: value, gradient and Hessian-vector product (src/pHNN.py:72-73, src/pHNN_canonical.py:208-215)
@@ -685,8 +729,8 @@ DEV void hnet_layer1(const float* L, Lane ln, f32x4 z, Act<HID / 16>& a1) {
 
 // Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
 // (q1 is overwritten) to keep the live register set at five activation vectors.
-template <int HID, int MM = MM_F32>
-DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
+template <int HID, int MM = MM_F32, bool WG = false>
+DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v, float* rec = nullptr) {
   using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
   float unscale = 1.0f;
@@ -726,6 +770,7 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
     f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3S + 16 * t + 4 * ln.q);  // w3 / S: w holds S * zdot2
     f32x4 a2 = tp.a2.v[t];
     f32x4 ad2 = dtanh(a2) * w.v[t];
+    if (WG) reinterpret_cast<f32x4*>(rec + 2 * T * 256)[t * 64 + ln.lane] = ad2 * unscale;
     w.v[t] = w3 * (a2 * ad2);  // -gdot2 / 2
   }
   Act<T> qd;
@@ -741,6 +786,7 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
   } else {
     sq_bwd<T, T>(qd, L + Y::oW2, ln, w);
   }
+  if (WG) store_rec_scaled<T>(rec + 3 * T * 256, ln, qd, unscale);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     qd.v[t] = __builtin_elementwise_fma(qd.v[t], dtanh(tp.a1.v[t]), tp.q1.v[t]);
@@ -788,8 +834,8 @@ DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, 
 // MM_F16X2: obar is normalised per rollout by a power of two (the map is linear), split hi/lo and STACKED along the
 // K = 32 of one MFMA: k-slots 0..15 carry hi(obar), 16..31 lo(obar), against [V2^T hi | V2^T hi]; a second MFMA adds
 // V2^T lo x hi(obar).  Two 16-cycle MFMAs per tile of hidden units instead of four 32-cycle f32 ones.
-template <int HID, int MM = MM_F32>
-DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&obar)[16]) {
+template <int HID, int MM = MM_F32, bool WG = false>
+DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&obar)[16], float* rec = nullptr) {
   using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
   Act<T> hb;
@@ -833,6 +879,7 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
   }
 #pragma unroll
   for (int t = 0; t < T; ++t) hb.v[t] = hb.v[t] * dtanh(h.v[t]);
+  if (WG) store_rec_scaled<T>(rec, ln, hb, Y::HF ? unscale : 1.0f);
   f32x4 xb = to4_rep<T>(L + Y::oV1T, ln, hb);
   return Y::HF ? xb * unscale : xb;
 }
@@ -909,10 +956,15 @@ struct PhnnModel {
     return dx;
   }
 
+  // weight-gradient record of one evaluation (WRec): a2, q1, ad2, qd, hbR [, hbG] + the per-rollout small vectors
+  static constexpr int NBIG = FIXG ? 5 : 6;
+  using Rec = WRec<T, NBIG>;
+
   // xbar = (df/dx)^T lam, ubar = (df/du)^T lam at (x,u); recomputes the forward tape it needs.
-  template <bool ST = false>
+  // WG: also writes the weight-gradient record of this evaluation to `rec` (Hbar = cotangent on H, adds Hbar dH to xbar).
+  template <bool ST = false, bool WG = false>
   DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar,
-                      const float* stash = nullptr) {
+                      const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     keep_lds_reads_local();
     HTape<HID> tp;
     float Hdummy;
@@ -924,6 +976,10 @@ struct PhnnModel {
       hnet_layer1<HID, MM>(L + oH, ln, x, tp.a1);
     } else {
       dH = hnet_grad<HID, false, MM>(L + oH, ln, x, tp, Hdummy);
+    }
+    if (WG) {
+      store_rec<T>(rec, ln, tp.a2);
+      store_rec<T>(rec + Rec::VEC, ln, tp.q1);
     }
     f32x4 xb = splat4(0.f);
     float S[N][N], Stl[N], StdH[N];
@@ -958,7 +1014,12 @@ struct PhnnModel {
           float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
           rbar[i * N + j] = (sij + sji) * 0.5f;
         }
-      xb += h1_bwd<HID, MM>(L + oR, ln, hR, rbar);
+      xb += h1_bwd<HID, MM, WG>(L + oR, ln, hR, rbar, WG ? rec + 4 * Rec::VEC : nullptr);
+      if (WG && ln.q == 0) {
+        f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm[4 + k] = f32x4{rbar[4 * k], rbar[4 * k + 1], rbar[4 * k + 2], rbar[4 * k + 3]};
+      }
     }
     ubar = 0.f;
     if (FIXG) {
@@ -975,7 +1036,7 @@ struct PhnnModel {
         ubar = __builtin_fmaf(gf[i], lam[i], ubar);
         gbar[i] = lam[i] * u;
       }
-      xb += h1_bwd<HID, MM>(L + oGn, ln, hG, gbar);
+      xb += h1_bwd<HID, MM, WG>(L + oGn, ln, hG, gbar, WG ? rec + 5 * Rec::VEC : nullptr);
     }
     // v = A^T lam, A = Jeff - S S^T
     f32x4 v = splat4(0.f);
@@ -988,7 +1049,16 @@ struct PhnnModel {
       for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[j][k], Stl[k], acc);
       v[j] = acc;
     }
-    xbar = xb + hnet_hvp<HID, MM>(L + oH, ln, tp, v);
+    if (WG && ln.q == 0) {
+      f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
+      sm[0] = x;
+      sm[1] = v;
+      sm[2] = lam;
+      sm[3] = dH;
+      sm[8] = f32x4{u, Hbar, 0.f, 0.f};
+    }
+    xbar = xb + hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
+    if (WG) xbar = xbar + Hbar * dH;
   }
 };
 
@@ -1001,8 +1071,8 @@ struct CanonModel {
   static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int oH = 0;
-  static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // [12]: a, b, c, 0, Rd[4], G[4]
-  static constexpr int IMG = oC + 12;
+  static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // [16]: a, b, c, 0, Rd[4], G[4], sigmoid(R_diag_raw)[4]
+  static constexpr int IMG = oC + 16;
 
   static constexpr int STASH = 2 * T * 256 + 64;
 
@@ -1029,9 +1099,13 @@ struct CanonModel {
                  mi01 * dp0 + mi11 * dp1};
   }
 
-  template <bool ST = false>
+  static constexpr int NBIG = 4;
+  using Rec = WRec<T, NBIG>;
+
+  // WG: also writes the weight-gradient record (a2, q1, ad2, qd; small: z, v, lam, dH, the two R_diag cotangents)
+  template <bool ST = false, bool WG = false>
   DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, float u, f32x4 lam, f32x4& ybar, float& ubar,
-                      const float* stash = nullptr) {
+                      const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     keep_lds_reads_local();
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
     float sn, cs;
@@ -1062,7 +1136,22 @@ struct CanonModel {
     float mb11 = lam[1] * z[3] + lam[3] * dp1;
     f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
     ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
-    f32x4 zb = hnet_hvp<HID, MM>(L + oH, ln, tp, v);
+    if (WG) {
+      store_rec<T>(rec, ln, tp.a2);
+      store_rec<T>(rec + Rec::VEC, ln, tp.q1);
+      if (ln.q == 0) {
+        f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
+        sm[0] = z;
+        sm[1] = v;
+        sm[2] = lam;
+        sm[3] = dH;
+        // d(lam^T f)/d Rd_{2,3}: dp_i = -dH_i - Rd_{2+i} dH_{2+i} + ...  (softplus' is applied by the reduce kernel)
+        sm[4] = f32x4{0.f, 0.f, -dpb0 * dH[2], -dpb1 * dH[3]};
+        sm[8] = f32x4{u, Hbar, 0.f, 0.f};
+      }
+    }
+    f32x4 zb = hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
+    if (WG) zb = zb + Hbar * dH;
     zb[2] += pb0;
     zb[3] += pb1;
     float bcb = zb[2] * y[3] + zb[3] * y[2];
@@ -1280,6 +1369,10 @@ struct RollParams {
   float* grad_u;       // (B,H)
   float* grad_x0;      // (B,N) or null
   float* stash;        // K1 -> K2 tape workspace (Euler only) or null: [tile][t][M::STASH] floats
+  const float* dx_bar;  // (B,H,N) or null: cotangent on the per-step derivatives f(x_t,u_t) (training losses on dX_pred)
+  float* dx_out;       // (B,H,N) or null: K1 also returns f(x_t,u_t) of every step (first stage)
+  float* wrec;         // weight-gradient records [tile][t][stage][M::Rec::SIZE] (adjoint kernels built with WG)
+  int no_cost;         // 1: no stage cost at all (training rollouts): cost cotangent 0, controls used as given
   long long B;
   int H;
   float dt, half_dt, sixth_dt;
@@ -1294,6 +1387,8 @@ struct PointParams {
   float* dx;         // (B,N)  forward: dx ; vjp: xbar
   float* Hout;       // (B)    forward: H (nullable) ; vjp: ubar
   long long B;
+  const float* Hbar;  // (B) or null: cotangent on H (WG vjp only)
+  float* wrec;        // weight-gradient records [tile][M::Rec::SIZE] (WG vjp only)
 };
 
 template <int IMG>
@@ -1353,6 +1448,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
     cost = __builtin_fmaf(u * p.c.R[0], u, cost);
     f32x4 k1 = M::template f<false, STASH>(L, scr, ln, x, u, Hd,
                                            STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr);
+    if (p.dx_out && writer) store_state<N>(p.dx_out + (b * p.H + t) * N, k1);
     if (INTEG == PHNN_INTEG_EULER) {
       x = x + p.dt * k1;
     } else {
@@ -1364,11 +1460,12 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
     cost += state_cost<N>(p.c, x);
     if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1) + t + 1) * N, x);
   }
-  if (writer) p.cost[b] = cost;
+  if (writer && p.cost) p.cost[b] = cost;
 }
 
-// K2: adjoint march over the states K1 stored.
-template <class M, int INTEG, bool STASH>
+// K2: adjoint march over the states K1 stored.  WG: every dynamics VJP also emits its weight-gradient record
+// (training side: k_wgrad_reduce sums them into d loss / d theta).
+template <class M, int INTEG, bool STASH, bool WG = false>
 __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int N = M::N;
@@ -1388,20 +1485,34 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   const bool writer = valid && ln.q == 0;
   const float* tr = p.traj_in + (b * (p.H + 1)) * N;
   const float* up = p.u + b * p.H;
-  const float cb = p.cost_bar ? p.cost_bar[b] : 1.0f;
+  const float cb = p.no_cost ? 0.0f : (p.cost_bar ? p.cost_bar[b] : 1.0f);
   const float* tb = p.traj_bar ? p.traj_bar + (b * (p.H + 1)) * N : nullptr;
+  const float* db = p.dx_bar ? p.dx_bar + (b * p.H) * N : nullptr;
+  // a padding lane (rollout index beyond the batch) must not contribute to the weight gradient: its cotangents are zeroed
+  const float live = valid ? 1.0f : 0.0f;
   f32x4 lam = cb * state_cost_grad<N>(p.c, load_state<N>(tr + (long long)p.H * N));
   if (tb) lam = lam + load_state<N>(tb + (long long)p.H * N);
+  if (WG) lam = lam * live;
+  constexpr int STAGES = INTEG == PHNN_INTEG_EULER ? 1 : 4;
   float Hd;
   for (int t = p.H - 1; t >= 0; --t) {
     f32x4 x = load_state<N>(tr + (long long)t * N);
     float uraw = up[t];
-    float u = clamp_u(p.c, uraw);
+    float u = p.no_cost ? uraw : clamp_u(p.c, uraw);
+    f32x4 dxb = splat4(0.f);
+    if (db) dxb = load_state<N>(db + (long long)t * N) * live;
     f32x4 xb;
     float ub, utot;
+    float* rec = nullptr;
+    if constexpr (WG) rec = p.wrec + ((tile * p.H + t) * STAGES) * (long long)M::Rec::SIZE;
     if (INTEG == PHNN_INTEG_EULER) {
-      M::template vjp<STASH>(L, scr, ln, x, u, p.dt * lam, xb, ub,
-                             STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr);
+      if constexpr (WG) {
+        M::template vjp<STASH, true>(L, scr, ln, x, u, p.dt * lam + dxb, xb, ub,
+                                     STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr, rec);
+      } else {
+        M::template vjp<STASH>(L, scr, ln, x, u, p.dt * lam + dxb, xb, ub,
+                               STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr);
+      }
       lam = lam + xb;
       utot = ub;
     } else {
@@ -1412,21 +1523,34 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
       f32x4 k3 = M::template f<false>(L, scr, ln, y3, u, Hd);
       f32x4 y4 = x + p.dt * k3;
       f32x4 yb4, yb3, yb2, yb1;
-      M::vjp(L, scr, ln, y4, u, p.sixth_dt * lam, yb4, ub);
-      utot = ub;
-      M::vjp(L, scr, ln, y3, u, (2.0f * p.sixth_dt) * lam + p.dt * yb4, yb3, ub);
-      utot += ub;
-      M::vjp(L, scr, ln, y2, u, (2.0f * p.sixth_dt) * lam + p.half_dt * yb3, yb2, ub);
-      utot += ub;
-      M::vjp(L, scr, ln, x, u, p.sixth_dt * lam + p.half_dt * yb2, yb1, ub);
-      utot += ub;
+      if constexpr (WG) {
+        M::template vjp<false, true>(L, scr, ln, y4, u, p.sixth_dt * lam, yb4, ub, nullptr, rec + 3 * M::Rec::SIZE);
+        utot = ub;
+        M::template vjp<false, true>(L, scr, ln, y3, u, (2.0f * p.sixth_dt) * lam + p.dt * yb4, yb3, ub, nullptr,
+                                     rec + 2 * M::Rec::SIZE);
+        utot += ub;
+        M::template vjp<false, true>(L, scr, ln, y2, u, (2.0f * p.sixth_dt) * lam + p.half_dt * yb3, yb2, ub, nullptr,
+                                     rec + 1 * M::Rec::SIZE);
+        utot += ub;
+        M::template vjp<false, true>(L, scr, ln, x, u, p.sixth_dt * lam + p.half_dt * yb2 + dxb, yb1, ub, nullptr, rec);
+        utot += ub;
+      } else {
+        M::vjp(L, scr, ln, y4, u, p.sixth_dt * lam, yb4, ub);
+        utot = ub;
+        M::vjp(L, scr, ln, y3, u, (2.0f * p.sixth_dt) * lam + p.dt * yb4, yb3, ub);
+        utot += ub;
+        M::vjp(L, scr, ln, y2, u, (2.0f * p.sixth_dt) * lam + p.half_dt * yb3, yb2, ub);
+        utot += ub;
+        M::vjp(L, scr, ln, x, u, p.sixth_dt * lam + p.half_dt * yb2 + dxb, yb1, ub);
+        utot += ub;
+      }
       lam = lam + yb1 + yb2 + yb3 + yb4;
     }
     lam = lam + cb * state_cost_grad<N>(p.c, x);
-    if (tb) lam = lam + load_state<N>(tb + (long long)t * N);
+    if (tb) lam = lam + load_state<N>(tb + (long long)t * N) * (WG ? live : 1.0f);
     float g = __builtin_fmaf(cb * (2.0f * p.c.R[0]), u, utot);
-    if (p.c.has_u_bounds && !(uraw >= p.c.u_min && uraw <= p.c.u_max)) g = 0.f;
-    if (writer) p.grad_u[b * p.H + t] = g;
+    if (!p.no_cost && p.c.has_u_bounds && !(uraw >= p.c.u_min && uraw <= p.c.u_max)) g = 0.f;
+    if (writer && p.grad_u) p.grad_u[b * p.H + t] = g;
   }
   if (p.grad_x0 && writer) store_state<N>(p.grad_x0 + b * N, lam);
 }
@@ -1458,7 +1582,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_forward(PointParams p)
   }
 }
 
-template <class M>
+template <class M, bool WG = false>
 __global__ __launch_bounds__(64 * kMaxWaves) void k_model_vjp(PointParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int N = M::N;
@@ -1478,13 +1602,332 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_vjp(PointParams p) {
     f32x4 lam = load_state<N>(p.lam + b * N);
     f32x4 xb;
     float ub;
-    M::vjp(lds, scr, ln, x, p.u[b], lam, xb, ub);
+    if constexpr (WG) {  // padding lanes carry zero cotangents: they add nothing to the weight gradient
+      const float live = valid ? 1.0f : 0.0f;
+      M::template vjp<false, true>(lds, scr, ln, x, p.u[b], lam * live, xb, ub, nullptr,
+                                   p.wrec + tile * (long long)M::Rec::SIZE, p.Hbar ? p.Hbar[b] * live : 0.0f);
+    } else {
+      M::vjp(lds, scr, ln, x, p.u[b], lam, xb, ub);
+    }
     if (valid && ln.q == 0) {
       store_state<N>(p.dx + b * N, xb);
       p.Hout[b] = ub;
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient reduction (training side): records -> d loss / d theta.
+//
+// Each gradient is a sum over evaluation points of outer products of per-point vectors (oracle/phnn_oracle.c
+// hnet_wgrad / mlp_wgrad state the algebra):
+//   W2bar = sum_p  gdot2* (x) a1 + g2 (x) adot1          b2bar = sum gdot2*        W3bar = sum adot2*
+//   W1bar = sum_p  gdot1* (x) x  + g1 (x) v              b1bar = sum gdot1*        b3bar = sum Hbar
+//   (x* = x + Hbar-weighted value term;  v = A^T lam;  dots = tangents along v, all rebuilt from the record)
+//   R_net: V2bar = sum rbar (x) hR, c2bar = sum rbar, V1bar = sum hbR (x) x, c1bar = sum hbR     (G_net alike)
+//   Jbar  = sum lam dH^T - dH lam^T
+// Mapping: one workgroup = T waves, wave w owns hidden units 16w..16w+15 of every vector, so all element-wise
+// algebra and every vector-shaped sum is lane-local (lane (i,q) reg r = unit 16w+4q+r of rollout i); sums over the 16
+// rollouts of a record are taken once, at the end.  The one matrix-shaped gradient, W2bar, is a GEMM with K = points:
+// the factor vectors are transposed through LDS (rollout index -> MFMA k index) and accumulated with exact-f32
+// v_mfma_f32_16x16x4_f32, wave w producing rows 16w.. of W2bar for all 16T columns (T tiles = 4T registers).
+// Workgroups stride over the records; each writes its partial gradient to its own slab row (padded-blob layout),
+// k_wgrad_finish sums the rows in a fixed order: bitwise reproducible, no atomics.
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float* img;
+  const float* rec;   // [n_rec][Rec::SIZE]
+  long long n_rec;
+  float* slab;        // [gridDim.x][PP]
+  int PP;
+};
+
+template <int T>
+DEV f32x4 tanh4_model(f32x4 z) {  // the model's own tanh of a pre-activation (tanh_act_pre)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (kPreScaled<T>) z[r] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z[r]) + 1.0f), 1.0f);
+    else z[r] = tanh_dev<true>(z[r]);
+  }
+  return z;
+}
+
+DEV float sum16(float v) {  // over the 16 rollout lanes (i) that share a q
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+// offsets of the padded weight blob (include/phnn_mpc.h order) -- what a slab row is laid out as
+template <int N, int HID>
+struct BlobMlp1 {  // in(N) -> HID -> OUT
+  int oV1, oC1, oV2, oC2, size;
+  __host__ __device__ constexpr BlobMlp1(int base, int OUT)
+      : oV1(base), oC1(base + HID * N), oV2(base + HID * N + HID), oC2(base + HID * N + HID + OUT * HID),
+        size(HID * N + HID + OUT * HID + OUT) {}
+};
+template <int N, int HID>
+struct BlobH {  // in(N) -> HID -> HID -> 1
+  int oW1, oB1, oW2, oB2, oW3, oB3, size;
+  __host__ __device__ constexpr BlobH(int base)
+      : oW1(base), oB1(base + HID * N), oW2(base + HID * N + HID), oB2(base + HID * N + HID + HID * HID),
+        oW3(base + HID * N + 2 * HID + HID * HID), oB3(base + HID * N + 3 * HID + HID * HID),
+        size(HID * N + 3 * HID + HID * HID + 1) {}
+};
+
+template <class M>
+struct BlobOf;
+template <int N, int HID, bool FIXG, int MM>
+struct BlobOf<PhnnModel<N, HID, FIXG, MM>> {
+  static constexpr int oJ = 0, oGfix = N * N;
+  static constexpr BlobMlp1<N, HID> R{N * N + (FIXG ? N : 0), N * N};
+  static constexpr BlobH<N, HID> H{R.oV1 + R.size};
+  static constexpr BlobMlp1<N, HID> G{H.oW1 + H.size, N};
+  static constexpr int SIZE = H.oW1 + H.size + (FIXG ? 0 : G.size);
+};
+template <int HID, int MM>
+struct BlobOf<CanonModel<HID, MM>> {
+  static constexpr int oRd = 0;  // R_diag_raw (4) | G (4) | log_a, b, log_c | H_net
+  static constexpr BlobH<4, HID> H{4 + 4 + 3};
+  static constexpr int SIZE = H.oW1 + H.size;
+};
+
+template <class M>
+struct IsPhnn { static constexpr bool value = false; };
+template <int N, int HID, bool FIXG, int MM>
+struct IsPhnn<PhnnModel<N, HID, FIXG, MM>> { static constexpr bool value = true; };
+
+// one-hidden-layer net (R_net / G_net) part of a record, for the units of this lane.  NOUT used outputs.
+template <int N, int HID, int MM, int NOUT>
+struct H1Acc {
+  f32x4 c1 = {0, 0, 0, 0};
+  f32x4 V1[4] = {};    // [c] : units on the vector
+  f32x4 V2[NOUT] = {};  // [o]
+  float c2[NOUT] = {};
+
+  DEV void add(const float* Lh1, int w, Lane ln, f32x4 x, f32x4 hb, const float (&obar)[NOUT]) {
+    using Y = LayH1<HID, MM>;
+    f32x4 c = *reinterpret_cast<const f32x4*>(Lh1 + Y::oC1 + 16 * w + 4 * ln.q);
+    f32x4 h = tanh4_model<HID / 16>(mfma(Lh1[Y::oV1f + w * 64 + ln.lane], sel4(x, ln.q), c));
+    c1 += hb;
+#pragma unroll
+    for (int k = 0; k < N; ++k) V1[k] += hb * x[k];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      V2[o] += h * obar[o];
+      c2[o] += obar[o];
+    }
+  }
+
+  DEV void write(float* row, const BlobMlp1<N, HID>& B, int w, Lane ln) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int unit = 16 * w + 4 * ln.q + r;
+      float s = sum16(c1[r]);
+      if (ln.i == 0) row[B.oC1 + unit] = s;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        float t = sum16(V1[k][r]);
+        if (ln.i == 0) row[B.oV1 + unit * N + k] = t;
+      }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        float t = sum16(V2[o][r]);
+        if (ln.i == 0) row[B.oV2 + o * HID + unit] = t;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      float t = sum16(c2[o]);
+      if (w == 0 && ln.lane == 0) row[B.oC2 + o] = t;
+    }
+  }
+};
+
+template <class M>
+__global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int N = M::N, HID = M::HID, T = M::T, MM = M::MM;
+  using Y = LayH2<HID, MM>;
+  using Rec = typename M::Rec;
+  using BL = BlobOf<M>;
+  constexpr bool PHNN = IsPhnn<M>::value;
+  // the hidden x hidden image (the first W2F floats of every model image) is not needed here: stage the rest
+  constexpr int SKIP = Y::W2F, KEEP = M::IMG - SKIP;
+  static_assert(M::oH == 0 && Y::oW2 == 0, "the W2 image leads the model image");
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.img + SKIP);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int k = threadIdx.x; k < KEEP / 4; k += blockDim.x) dst[k] = src[k];
+  }
+  const float* L = lds - SKIP;  // image offsets stay valid for everything behind the W2 image
+  const int w = threadIdx.x >> 6;
+  Lane ln;
+  ln.lane = threadIdx.x & 63;
+  ln.i = ln.lane & 15;
+  ln.q = ln.lane >> 4;
+  // exchange buffers: two arrays (A side: gdot2* | g2, B side: a1 | adot1) of [HID units][32 k] f32, k stored at
+  // position (k & 3) * 8 + (k >> 2) so that lane (i,q) finds the operands of its 8 k-steps contiguously; x2 (ping-pong)
+  constexpr int XLD = 36;  // floats per unit row (32 + pad)
+  float* X = lds + KEEP;
+  constexpr int XSZ = HID * XLD;
+  __syncthreads();
+  const float S = 2.8853900817779268f / L[Y::oB3 + 1], k1inv = L[Y::oB3 + 2], Sb = L[Y::oB3 + 3];
+  const float c_ad2 = k1inv / S, c_q1 = 1.0f / (S * Sb), c_qd = -2.0f * k1inv / (S * Sb);
+  const f32x4 b1v = *reinterpret_cast<const f32x4*>(L + Y::oB1 + 16 * w + 4 * ln.q);
+  const f32x4 w3v = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * w + 4 * ln.q);
+  const float w1f = L[Y::oW1f + w * 64 + ln.lane];
+
+  f32x4 accW2[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) accW2[t] = splat4(0.f);
+  f32x4 aW3 = splat4(0.f), aB2 = splat4(0.f), aB1 = splat4(0.f), aW1[4] = {};
+  float aB3 = 0.f, aJ[N * N] = {}, aRd[2] = {};
+  H1Acc<N, HID, MM, PHNN ? N * N : 1> accR;
+  H1Acc<N, HID, MM, N> accG;
+
+  int buf = 0;
+  for (long long r = blockIdx.x; r < p.n_rec; r += gridDim.x, buf ^= 1) {
+    const float* R = p.rec + r * (long long)Rec::SIZE;
+    const f32x4* big = reinterpret_cast<const f32x4*>(R) + w * 64 + ln.lane;
+    const f32x4 a2 = big[0], q1r = big[Rec::VEC / 4], ad2r = big[2 * (Rec::VEC / 4)], qdr = big[3 * (Rec::VEC / 4)];
+    const f32x4* sm = reinterpret_cast<const f32x4*>(R + Rec::oSmall + ln.i * kRecSmall);
+    const f32x4 x = sm[0], v = sm[1], lam = sm[2], dH = sm[3], misc = sm[8];
+    const float Hbar = misc[1];
+    // H_net factors of this lane's 4 units
+    const f32x4 a1 = tanh4_model<T>(mfma(w1f, sel4(x, ln.q), b1v));
+    const f32x4 d1 = dtanh(a1), d2 = dtanh(a2);
+    const f32x4 ad1 = d1 * mfma(w1f, sel4(v, ln.q), splat4(0.f)) * k1inv;
+    const f32x4 ad2 = ad2r * c_ad2;
+    const f32x4 g2 = w3v * d2;
+    const f32x4 gd2 = (-2.0f * w3v) * (a2 * ad2) + Hbar * g2;
+    const f32x4 q1 = q1r * c_q1;
+    const f32x4 g1 = q1 * d1;
+    const f32x4 gd1 = (qdr * c_qd) * d1 - 2.0f * q1 * (a1 * ad1) + Hbar * g1;
+    aW3 += ad2 + Hbar * a2;
+    aB2 += gd2;
+    aB1 += gd1;
+#pragma unroll
+    for (int k = 0; k < N; ++k) aW1[k] += gd1 * x[k] + g1 * v[k];
+    if (w == 0 && ln.q == 0) {
+      aB3 += Hbar;
+      if (PHNN) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+          for (int j = 0; j < N; ++j) aJ[i * N + j] += lam[i] * dH[j] - lam[j] * dH[i];
+      } else {
+        const f32x4 rd = sm[4];
+        aRd[0] += rd[2];
+        aRd[1] += rd[3];
+      }
+    }
+    if constexpr (PHNN) {
+      float rbar[N * N];
+#pragma unroll
+      for (int k = 0; k < (N * N + 3) / 4; ++k) {
+        const f32x4 t = sm[4 + k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * k + e < N * N) rbar[4 * k + e] = t[e];
+      }
+      accR.add(L + M::oR, w, ln, x, big[4 * (Rec::VEC / 4)], rbar);
+      if constexpr (!M::FIXG) {
+        float gbar[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) gbar[i] = lam[i] * misc[0];
+        accG.add(L + M::oGn, w, ln, x, big[5 * (Rec::VEC / 4)], gbar);
+      }
+    }
+    // transpose the W2bar factors through LDS: [unit][pos(k)], k = rollout (term 1) / 16 + rollout (term 2)
+    float* XG = X + buf * 2 * XSZ;
+    float* XA = XG + XSZ;
+    const int p1 = (ln.i & 3) * 8 + (ln.i >> 2), p2 = p1 + 4;  // pos(i), pos(16 + i)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int unit = 16 * w + 4 * ln.q + rr;
+      XG[unit * XLD + p1] = gd2[rr];
+      XG[unit * XLD + p2] = g2[rr];
+      XA[unit * XLD + p1] = a1[rr];
+      XA[unit * XLD + p2] = ad1[rr];
+    }
+    __syncthreads();
+    // rows 16w.. of W2bar: A = XG[16w + i][k], B = XA[16nt + i][k], k-step s <-> k = 4s + q <-> position 8q + s
+    const f32x4* ga = reinterpret_cast<const f32x4*>(XG + (16 * w + ln.i) * XLD + 8 * ln.q);
+    const f32x4 g0 = ga[0], g1v = ga[1];
+#pragma unroll
+    for (int nt = 0; nt < T; ++nt) {
+      const f32x4* ba = reinterpret_cast<const f32x4*>(XA + (16 * nt + ln.i) * XLD + 8 * ln.q);
+      const f32x4 b0 = ba[0], b1 = ba[1];
+      f32x4 acc = accW2[nt];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = mfma(g0[s2], b0[s2], acc);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = mfma(g1v[s2], b1[s2], acc);
+      accW2[nt] = acc;
+    }
+  }
+  // ---- write this workgroup's partial gradient (every entry of its row that carries a gradient)
+  float* row = p.slab + (long long)blockIdx.x * p.PP;
+  constexpr BlobH<N, HID> BH = BL::H;
+#pragma unroll
+  for (int nt = 0; nt < T; ++nt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) row[BH.oW2 + (16 * w + 4 * ln.q + rr) * HID + 16 * nt + ln.i] = accW2[nt][rr];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int unit = 16 * w + 4 * ln.q + rr;
+    float s3 = sum16(aW3[rr]), s2 = sum16(aB2[rr]), s1 = sum16(aB1[rr]);
+    if (ln.i == 0) {
+      row[BH.oW3 + unit] = s3;
+      row[BH.oB2 + unit] = s2;
+      row[BH.oB1 + unit] = s1;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float t = sum16(aW1[k][rr]);
+      if (ln.i == 0) row[BH.oW1 + unit * N + k] = t;
+    }
+  }
+  {
+    float t = sum16(aB3);
+    if (w == 0 && ln.lane == 0) row[BH.oB3] = t;
+  }
+  if constexpr (PHNN) {
+#pragma unroll
+    for (int k = 0; k < N * N; ++k) {
+      float t = sum16(aJ[k]);
+      if (w == 0 && ln.lane == 0) row[BL::oJ + k] = t;
+    }
+    accR.write(row, BL::R, w, ln);
+    if constexpr (!M::FIXG) accG.write(row, BL::G, w, ln);
+  } else {
+    // R_diag_raw: only rows 2, 3 reach the output; softplus' = sigmoid(raw) (image constants oC[12..15])
+    float t2 = sum16(aRd[0]), t3 = sum16(aRd[1]);
+    if (w == 0 && ln.lane == 0) {
+      row[BL::oRd + 0] = 0.f;  // rows 0, 1 of R multiply the dq rows the reference discards: zero gradient
+      row[BL::oRd + 1] = 0.f;
+      row[BL::oRd + 2] = t2 * L[M::oC + 14];
+      row[BL::oRd + 3] = t3 * L[M::oC + 15];
+    }
+  }
+}
+
+#ifdef PHNN_WGRAD_UNIT  // non-template kernel: defined in phnn_wgrad.hip only
+// out[j] (+)= sum over slab rows of the padded-blob entry map[j] (map[j] < 0: a buffer / autograd constant -> 0).
+// Fixed summation order: bitwise reproducible.
+__global__ void k_wgrad_finish(const float* slab, int rows, int PP, const int* map, int P, float* out, int accumulate) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  const int src = map[j];
+  float s = 0.f;
+  if (src >= 0)
+    for (int g = 0; g < rows; ++g) s += slab[(long long)g * PP + src];
+  out[j] = accumulate ? out[j] + s : s;
+}
+#endif  // PHNN_WGRAD_UNIT
 
 // K3: Adam on the controls + best-iterate tracking (torch.optim.Adam single-tensor order)
 struct AdamParams {

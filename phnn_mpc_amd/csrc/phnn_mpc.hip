@@ -328,6 +328,7 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   dst[Y::oB3] = b3[0];
   dst[Y::oB3 + 1] = 2.8853900817779268f / S;
   dst[Y::oB3 + 2] = 1.0f / k1;
+  dst[Y::oB3 + 3] = Sb;
   return p;
 }
 
@@ -466,6 +467,52 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
   return true;
 }
 
+// Index map of the width padding: for every entry of the ORIGINAL blob, its position in the padded blob (pad_model
+// embeds layers by rows/columns; same walk as pad_mlp, on indices).  The weight-gradient kernels produce the padded
+// blob's gradient; k_wgrad_finish gathers through this map.  Entries that carry no gradient in the reference (buffers:
+// G_fixed, the canonical G; CartPoleMassMatrix parameters, constants to autograd) map to -1.
+void map_mlp(std::vector<int>& map, size_t& o_off, size_t& p_off, const phnn_mlp_shape& s, int in, int outdim, int W) {
+  int last = in, last_p = in;
+  for (int l = 0; l <= s.depth; ++l) {
+    int o = l < s.depth ? s.hidden[l] : outdim, o_p = l < s.depth ? W : outdim;
+    for (int r = 0; r < o; ++r)
+      for (int c = 0; c < last; ++c) map[o_off + (size_t)r * last + c] = (int)(p_off + (size_t)r * last_p + c);
+    o_off += (size_t)o * last;
+    p_off += (size_t)o_p * last_p;
+    for (int r = 0; r < o; ++r) map[o_off + r] = (int)(p_off + r);
+    o_off += o;
+    p_off += o_p;
+    last = o;
+    last_p = o_p;
+  }
+}
+
+std::vector<int> unpad_map(const phnn_desc* d, const phnn_desc* pd) {
+  std::vector<int> map(weight_count(d), -1);
+  int n = d->n, m = d->m;
+  size_t o = 0, p = 0;
+  if (d->kind == PHNN_MODEL_PHNN) {
+    const int W = pd->h_net.hidden[0];
+    for (int k = 0; k < n * n; ++k) map[o + k] = (int)(p + k);  // J
+    o += (size_t)n * n;
+    p += (size_t)n * n;
+    if (d->fixed_G) {  // buffer
+      o += (size_t)n * m;
+      p += (size_t)n * m;
+    }
+    map_mlp(map, o, p, d->r_net, n, n * n, W);
+    map_mlp(map, o, p, d->h_net, n, 1, W);
+    if (!d->fixed_G) map_mlp(map, o, p, d->g_net, n, n * m, W);
+  } else if (d->kind == PHNN_MODEL_CANONICAL) {
+    const int W = pd->h_net.hidden[0];
+    for (int k = 0; k < n; ++k) map[o + k] = (int)(p + k);  // R_diag_raw
+    o += (size_t)n + (size_t)n * m + 3;                     // G: buffer; log_a, b, log_c: constants to autograd
+    p += (size_t)n + (size_t)n * m + 3;
+    map_mlp(map, o, p, d->h_net, n, 1, W);
+  }
+  return map;
+}
+
 float softplus_host(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 template <class M>
@@ -483,6 +530,8 @@ void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
   c[2] = expf(log_c) + 1e-3f;
   for (int i = 0; i < 4; ++i) c[4 + i] = softplus_host(Rd[i]) + 1e-4f;  // src/pHNN_canonical.py:162
   for (int i = 0; i < 4; ++i) c[8 + i] = G[i];
+  // softplus'(raw) = sigmoid(raw) (threshold 20 as torch.nn.functional.softplus): the weight-gradient kernels need it
+  for (int i = 0; i < 4; ++i) c[12 + i] = Rd[i] > 20.f ? 1.0f : (float)(1.0 / (1.0 + std::exp(-(double)Rd[i])));
 }
 
 template <class M>
@@ -566,6 +615,10 @@ struct phnn_handle {
   int device;
   int variant;
   KernelSet ks;
+  WgradSet wg;       // weight-gradient kernels (has_wgrad)
+  bool has_wgrad;
+  int* d_unpad;      // index map original blob -> padded blob (k_wgrad_finish)
+  int n_params;      // floats of the original blob
   float* d_img;
   float* h_img;      // pinned staging copy of the image (phnn_update_weights uploads from it asynchronously)
   size_t img_floats;
@@ -712,7 +765,10 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   h->max_waves = opt.max_waves > 0 ? opt.max_waves : kMaxWaves;
   h->d_img = nullptr;
   h->h_img = nullptr;
+  h->d_unpad = nullptr;
+  h->n_params = (int)n_floats;
   kernel_set(v, &h->ks);
+  h->has_wgrad = phnn_wgrad_kernels(v, &h->wg);
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device);
   h->n_cu = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -729,6 +785,12 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   if (e == hipSuccess) e = allow_big_lds(h->ks.grad_stash);
   if (e == hipSuccess) e = allow_big_lds(h->ks.mfwd);
   if (e == hipSuccess) e = allow_big_lds(h->ks.mvjp);
+  if (h->has_wgrad) {
+    if (e == hipSuccess) e = allow_big_lds(h->wg.grad[0]);
+    if (e == hipSuccess) e = allow_big_lds(h->wg.grad[1]);
+    if (e == hipSuccess) e = allow_big_lds(h->wg.mvjp);
+    if (e == hipSuccess) e = allow_big_lds(h->wg.reduce);
+  }
   if (e != hipSuccess) {
     delete h;
     return hip_fail(nullptr, e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -743,8 +805,14 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
     memcpy(h->h_img, img.data(), sizeof(float) * img.size());
     e = hipMemcpy(h->d_img, h->h_img, sizeof(float) * img.size(), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && h->has_wgrad) {
+    std::vector<int> map = unpad_map(desc, &pdesc);
+    e = hipMalloc(reinterpret_cast<void**>(&h->d_unpad), sizeof(int) * map.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_unpad, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     if (h->h_img) (void)hipHostFree(h->h_img);
+    if (h->d_unpad) (void)hipFree(h->d_unpad);
     (void)hipFree(h->d_img);
     delete h;
     return hip_fail(nullptr, e, "upload of the weights image");
@@ -777,6 +845,7 @@ int phnn_destroy(phnn_handle* h) {
   if (!h) return PHNN_OK;
   if (h->d_img) (void)hipFree(h->d_img);
   if (h->h_img) (void)hipHostFree(h->h_img);
+  if (h->d_unpad) (void)hipFree(h->d_unpad);
   delete h;
   return PHNN_OK;
 }
@@ -787,7 +856,7 @@ int phnn_model_forward(phnn_handle* h, const float* x_dev, const float* u_dev, i
   if (B == 0) return PHNN_OK;
   if (!x_dev || !u_dev || !dx_dev || B < 0) return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
   PHNN_ON_DEVICE(h);
-  PointParams p{h->d_img, x_dev, u_dev, nullptr, dx_dev, H_dev, (long long)B};
+  PointParams p{h->d_img, x_dev, u_dev, nullptr, dx_dev, H_dev, (long long)B, nullptr, nullptr};
   return launch(h, h->ks.mfwd, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
 }
 
@@ -798,7 +867,7 @@ int phnn_model_vjp(phnn_handle* h, const float* x_dev, const float* u_dev, const
   if (!x_dev || !u_dev || !lam_dev || !xbar_dev || !ubar_dev || B < 0)
     return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor or negative batch");
   PHNN_ON_DEVICE(h);
-  PointParams p{h->d_img, x_dev, u_dev, lam_dev, xbar_dev, ubar_dev, (long long)B};
+  PointParams p{h->d_img, x_dev, u_dev, lam_dev, xbar_dev, ubar_dev, (long long)B, nullptr, nullptr};
   return launch(h, h->ks.mvjp, p, (B + kTileB - 1) / kTileB, true, (hipStream_t)stream);
 }
 
@@ -873,6 +942,109 @@ int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   p.stash = stash ? (float*)workspace_dev : nullptr;
   return launch(h, stash ? h->ks.grad_stash : h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false,
                 (hipStream_t)stream);
+}
+
+// ---- training side --------------------------------------------------------------------------
+static long long wgrad_records(int64_t B, int32_t H, int32_t integrator) {
+  long long tiles = (B + kTileB - 1) / kTileB;
+  if (H <= 0) return tiles;  // point mode
+  return tiles * (long long)H * (integrator == PHNN_INTEG_RK4 ? 4 : 1);
+}
+static int wgrad_rows(const phnn_handle* h, long long n_rec) {
+  long long rows = n_rec < (long long)h->n_cu ? n_rec : (long long)h->n_cu;
+  return (int)(rows < 1 ? 1 : rows);
+}
+
+size_t phnn_wgrad_workspace_bytes(const phnn_handle* h, int64_t B, int32_t H, int32_t integrator) {
+  if (!h || !h->has_wgrad || B <= 0) return 0;
+  long long n_rec = wgrad_records(B, H, integrator);
+  return sizeof(float) * ((size_t)n_rec * (size_t)h->wg.rec_floats + (size_t)wgrad_rows(h, n_rec) * (size_t)h->wg.blob_floats);
+}
+
+static int wgrad_reduce(phnn_handle* h, void* workspace_dev, long long n_rec, float* grad_theta_dev, int accumulate,
+                        hipStream_t st) {
+  float* rec = (float*)workspace_dev;
+  float* slab = rec + (size_t)n_rec * (size_t)h->wg.rec_floats;
+  const int rows = wgrad_rows(h, n_rec);
+  WgradParams wp{h->d_img, rec, n_rec, slab, h->wg.blob_floats};
+  hipLaunchKernelGGL(h->wg.reduce, dim3((unsigned)rows), dim3(64 * h->wg.reduce_waves), (size_t)h->wg.reduce_lds_bytes, st, wp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "wgrad reduce launch");
+  e = phnn_wgrad_finish(slab, rows, h->wg.blob_floats, h->d_unpad, h->n_params, grad_theta_dev, accumulate, st);
+  if (e != hipSuccess) return hip_fail(h, e, "wgrad finish launch");
+  return PHNN_OK;
+}
+
+int phnn_rollout_trajectory(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                            int32_t integrator, float dt, float* traj_dev, float* dx_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  phnn_cost neutral;
+  memset(&neutral, 0, sizeof neutral);
+  RollParams p;
+  if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, &neutral, integrator, dt)) return rc;
+  if (B == 0) return PHNN_OK;
+  if (!traj_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev is NULL");
+  PHNN_ON_DEVICE(h);
+  p.traj = traj_dev;
+  p.dx_out = dx_dev;
+  p.no_cost = 1;
+  return launch(h, h->ks.fwd[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+}
+
+int phnn_rollout_wgrad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H, int32_t integrator,
+                       float dt, const float* traj_dev, const float* traj_bar_dev, const float* dx_bar_dev,
+                       void* workspace_dev, float* grad_theta_dev, int32_t accumulate, float* grad_u_dev,
+                       float* grad_x0_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!h->has_wgrad)
+    return fail(h, PHNN_ERR_UNSUPPORTED, "no weight-gradient kernels for this model variant (pHNN and canonical pHNN have them)");
+  phnn_cost neutral;
+  memset(&neutral, 0, sizeof neutral);
+  RollParams p;
+  if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, &neutral, integrator, dt)) return rc;
+  if (!grad_theta_dev) return fail(h, PHNN_ERR_INVALID_ARG, "grad_theta_dev is NULL");
+  PHNN_ON_DEVICE(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(grad_theta_dev, 0, sizeof(float) * (size_t)h->n_params, st);
+      if (e != hipSuccess) return hip_fail(h, e, "hipMemsetAsync");
+    }
+    return PHNN_OK;
+  }
+  if (!traj_dev || !workspace_dev) return fail(h, PHNN_ERR_INVALID_ARG, "traj_dev / workspace_dev is NULL");
+  p.traj_in = traj_dev;
+  p.traj_bar = traj_bar_dev;
+  p.dx_bar = dx_bar_dev;
+  p.grad_u = grad_u_dev;
+  p.grad_x0 = grad_x0_dev;
+  p.no_cost = 1;
+  p.wrec = (float*)workspace_dev;
+  if (int rc = launch(h, h->wg.grad[integrator], p, (B + kTileB - 1) / kTileB, false, st)) return rc;
+  return wgrad_reduce(h, workspace_dev, wgrad_records(B, H, integrator), grad_theta_dev, accumulate, st);
+}
+
+int phnn_model_wgrad(phnn_handle* h, const float* x_dev, const float* u_dev, const float* lam_dev, const float* Hbar_dev,
+                     int64_t N, void* workspace_dev, float* grad_theta_dev, int32_t accumulate, float* xbar_dev,
+                     float* ubar_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!h->has_wgrad)
+    return fail(h, PHNN_ERR_UNSUPPORTED, "no weight-gradient kernels for this model variant (pHNN and canonical pHNN have them)");
+  if (N < 0 || !grad_theta_dev) return fail(h, PHNN_ERR_INVALID_ARG, "negative batch or grad_theta_dev is NULL");
+  PHNN_ON_DEVICE(h);
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) {
+    if (!accumulate) {
+      hipError_t e = hipMemsetAsync(grad_theta_dev, 0, sizeof(float) * (size_t)h->n_params, st);
+      if (e != hipSuccess) return hip_fail(h, e, "hipMemsetAsync");
+    }
+    return PHNN_OK;
+  }
+  if (!x_dev || !u_dev || !lam_dev || !workspace_dev || !xbar_dev || !ubar_dev)
+    return fail(h, PHNN_ERR_INVALID_ARG, "NULL tensor");
+  PointParams p{h->d_img, x_dev, u_dev, lam_dev, xbar_dev, ubar_dev, (long long)N, Hbar_dev, (float*)workspace_dev};
+  if (int rc = launch(h, h->wg.mvjp, p, (N + kTileB - 1) / kTileB, true, st)) return rc;
+  return wgrad_reduce(h, workspace_dev, wgrad_records(N, 0, 0), grad_theta_dev, accumulate, st);
 }
 
 int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev,

@@ -66,6 +66,22 @@ struct GradSet {
 // defined in phnn_grad.hip
 bool phnn_grad_kernels(int variant, GradSet* g);
 
+// Weight-gradient kernels (training side), defined in phnn_wgrad.hip for the pHNN and canonical
+// variants: the adjoint kernels built with the record flag (recompute mode) and the record reduction.
+struct WgradSet {
+  void (*grad[2])(RollParams);  // K2 + records: Euler, RK4
+  void (*mvjp)(PointParams);    // single-evaluation VJP + record
+  void (*reduce)(WgradParams);
+  int rec_floats;     // floats per record
+  int blob_floats;    // floats per slab row = size of the (width-padded) weight blob
+  int reduce_waves;   // waves per workgroup of the reduce kernel (= hidden width / 16)
+  int reduce_lds_bytes;
+};
+bool phnn_wgrad_kernels(int variant, WgradSet* g);  // false: no weight-gradient kernels for this variant
+// launches k_wgrad_finish (phnn_wgrad.hip); returns the launch status
+hipError_t phnn_wgrad_finish(const float* slab, int rows, int PP, const int* map, int P, float* out, int accumulate,
+                             hipStream_t stream);
+
 #define PHNN_FOR_EACH_VARIANT(X)                                                                                       \
   X(V_PHNN_4_128_FIX, M_PHNN_4_128_FIX, "phnn<n=4,hid=128,fixedG>") \
   X(V_PHNN_4_64_FIX, M_PHNN_4_64_FIX, "phnn<n=4,hid=64,fixedG>") \

@@ -45,6 +45,8 @@ class RolloutEngine:
             raise PhnnError("no GPU visible to torch; the rollout engine has no CPU fallback")
         self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind, activation=activation)
         self.n, self.m, self.kind = self.desc.n, self.desc.m, self.desc.kind
+        self.layout = weights.blob_layout(state_dict, kind=self.kind)  # [(state_dict key, offset, shape)] of the blob
+        self._wg_ws = None
         if matmul is None:
             matmul = os.environ.get("PHNN_MATMUL", "default")
             force_matmul = force_matmul or "PHNN_MATMUL" in os.environ  # an explicit environment override is a force
@@ -207,6 +209,77 @@ class RolloutEngine:
                                        self._p(gx), self._stream())
         _check(self.lib, self.h, rc)
         return gu, gx
+
+    # ------------------------------------------------------------------ training side: parameter gradients (row f4)
+    @property
+    def has_wgrad(self):
+        """True when the handle has weight-gradient kernels (pHNN and canonical pHNN variants)."""
+        return self.lib.phnn_wgrad_workspace_bytes(self.h, 16, 1, 0) > 0
+
+    def _wgrad_workspace(self, B, H, integ):
+        need = int(self.lib.phnn_wgrad_workspace_bytes(self.h, int(B), int(H), int(integ)))
+        if need == 0 and B > 0:
+            raise PhnnError("this model variant has no weight-gradient kernels (pHNN and canonical pHNN have them)")
+        if self._wg_ws is None or self._wg_ws.numel() < need:
+            self._wg_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        return self._wg_ws
+
+    def rollout_trajectory(self, x0, u, integrator="euler", dt=0.02, want_dx=False):
+        """Training rollout (no clamp, no cost): x0 (B,n), u (B,H,m) -> traj (B,H+1,n) [, dX (B,H,n) = f(x_t,u_t)]."""
+        x0 = self._t(x0, (-1, self.n))
+        B = x0.shape[0]
+        u, H = self._controls(u, B)
+        traj = torch.empty(B, H + 1, self.n, dtype=torch.float32, device=self.device)
+        dX = torch.empty(B, H, self.n, dtype=torch.float32, device=self.device) if want_dx else None
+        rc = self.lib.phnn_rollout_trajectory(self.h, self._p(x0), self._p(u), B, H, self._integ(integrator), float(dt),
+                                              self._p(traj), self._p(dX), self._stream())
+        _check(self.lib, self.h, rc)
+        return (traj, dX) if want_dx else traj
+
+    def rollout_wgrad(self, x0, u, traj, integrator="euler", dt=0.02, traj_bar=None, dx_bar=None, grad_theta=None,
+                      accumulate=False):
+        """Reverse pass of a training rollout: cotangents on the trajectory (B,H+1,n) and on the per-step derivatives
+        (B,H,n) -> (grad_theta (P,) in weight-blob layout, grad_u (B,H,m), grad_x0 (B,n))."""
+        x0 = self._t(x0, (-1, self.n))
+        B = x0.shape[0]
+        u, H = self._controls(u, B)
+        integ = self._integ(integrator)
+        traj = self._t(traj, (B, H + 1, self.n))
+        tb = self._t(traj_bar, (B, H + 1, self.n)) if traj_bar is not None else None
+        db = self._t(dx_bar, (B, H, self.n)) if dx_bar is not None else None
+        if grad_theta is None:
+            grad_theta = torch.empty(self.blob.size, dtype=torch.float32, device=self.device)
+            accumulate = False
+        gu = torch.empty(B, H, self.m, dtype=torch.float32, device=self.device)
+        gx = torch.empty(B, self.n, dtype=torch.float32, device=self.device)
+        ws = self._wgrad_workspace(B, H, integ)
+        rc = self.lib.phnn_rollout_wgrad(self.h, self._p(x0), self._p(u), B, H, integ, float(dt), self._p(traj),
+                                         self._p(tb), self._p(db), self._p(ws), self._p(grad_theta), int(accumulate),
+                                         self._p(gu), self._p(gx), self._stream())
+        _check(self.lib, self.h, rc)
+        return grad_theta, gu, gx
+
+    def model_wgrad(self, x, u, lam, Hbar=None, grad_theta=None, accumulate=False):
+        """Single evaluations: -> (grad_theta (P,) of sum lam.f + Hbar H, xbar (N,n), ubar (N,m))."""
+        x = self._t(x, (-1, self.n))
+        u = self._t(u, (-1, self.m))
+        lam = self._t(lam, (-1, self.n))
+        N = x.shape[0]
+        hb = self._t(Hbar, (N,)) if Hbar is not None else None
+        if grad_theta is None:
+            grad_theta = torch.empty(self.blob.size, dtype=torch.float32, device=self.device)
+            accumulate = False
+        xb = torch.empty_like(x)
+        ub = torch.empty(N, self.m, dtype=torch.float32, device=self.device)
+        ws = self._wgrad_workspace(N, 0, 0)
+        rc = self.lib.phnn_model_wgrad(self.h, self._p(x), self._p(u), self._p(lam), self._p(hb), N, self._p(ws),
+                                       self._p(grad_theta), int(accumulate), self._p(xb), self._p(ub), self._stream())
+        _check(self.lib, self.h, rc)
+        return grad_theta, xb, ub
+
+    def named_grads(self, grad_theta):
+        """{state_dict key: tensor view of the parameter's shape} of a gradient blob."""
+        return weights.unpack_grad_blob(None, grad_theta, layout=self.layout)
 
     # ------------------------------------------------------------------ Adam on the controls (K3)
     def adam_step(self, u, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, cost=None,

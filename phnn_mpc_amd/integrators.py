@@ -8,7 +8,7 @@ differentiable w.r.t. y0 and controls through the adjoint kernel (phnn_rollout_v
 import torch
 
 from . import _capi
-from .models import _EngineBacked, ODEFunc
+from .models import _EngineBacked, ODEFunc, _no_wgrad_warning, grad_params, split_param_grads
 
 
 def _call(model, y, u):
@@ -47,28 +47,52 @@ def _zero_cost(n, m):
 
 
 class _RolloutFn(torch.autograd.Function):
-    """trajectory = rollout(y0, controls) on K1; backward = general adjoint (traj cotangent) on K2."""
+    """(trajectory, dX) = rollout(y0, controls) on K1.  backward: the adjoint march on K2 -- w.r.t. y0 and controls,
+    and, when the model's parameters require grad or the loss uses dX, the weight-gradient path (phnn_rollout_wgrad):
+    what loss.backward() does in the reference's training loops (scripts/train_cartpole_phnn.py:112-178, main.py:93-148).
+    """
 
     @staticmethod
-    def forward(ctx, y0, controls, model, dt, integrator):
+    def forward(ctx, y0, controls, model, dt, integrator, keys, *params):
         eng = model.engine
         y0d = y0.detach().to(eng.device, torch.float32).contiguous()
         ud = controls.detach().to(eng.device, torch.float32).contiguous()
-        cost = _zero_cost(eng.n, eng.m)
-        _, traj = eng.rollout_cost(y0d, ud, cost, integrator, dt, want_traj=True)
-        ctx.model, ctx.dt, ctx.integ, ctx.cost = model, dt, integrator, cost
-        ctx.devs = (y0.device, controls.device)
+        traj, dX = eng.rollout_trajectory(y0d, ud, integrator, dt, want_dx=True)
+        ctx.model, ctx.dt, ctx.integ, ctx.keys = model, dt, integrator, keys
+        ctx.devs = (y0.device, controls.device, params[0].device if params else None)
         ctx.save_for_backward(y0d, ud, traj)
-        return traj.to(y0.device)
+        ctx.set_materialize_grads(False)  # an unused output (dX, mostly) arrives as None, not as zeros
+        return traj.to(y0.device), dX.to(y0.device)
 
     @staticmethod
-    def backward(ctx, gtraj):
+    def backward(ctx, gtraj, gdx):
         y0d, ud, traj = ctx.saved_tensors
         eng = ctx.model.engine
+        want_params = bool(ctx.keys) and any(ctx.needs_input_grad[6:])
+        nk = len(ctx.keys)
+        tb = None if gtraj is None else gtraj.to(eng.device, torch.float32).contiguous()
+        db = None if gdx is None else gdx.to(eng.device, torch.float32).contiguous()
+        if want_params or (db is not None and eng.has_wgrad):
+            gth, gu, gx = eng.rollout_wgrad(y0d, ud, traj, ctx.integ, ctx.dt, traj_bar=tb, dx_bar=db)
+            pg = split_param_grads(eng, gth, ctx.keys, ctx.devs[2]) if want_params else (None,) * nk
+            return (gx.to(ctx.devs[0]), gu.to(ctx.devs[1]), None, None, None, None) + pg
+        if db is not None and bool((db != 0).any()):
+            raise NotImplementedError("a loss on the per-step derivatives needs the weight-gradient kernels (pHNN / canonical)")
         zero = torch.zeros(y0d.shape[0], dtype=torch.float32, device=eng.device)
-        gu, gx = eng.rollout_vjp(y0d, ud, traj, ctx.cost, ctx.integ, ctx.dt,
-                                 traj_bar=gtraj.to(eng.device, torch.float32).contiguous(), cost_bar=zero)
-        return gx.to(ctx.devs[0]), gu.to(ctx.devs[1]), None, None, None
+        if tb is None:
+            tb = torch.zeros_like(traj)
+        gu, gx = eng.rollout_vjp(y0d, ud, traj, _zero_cost(eng.n, eng.m), ctx.integ, ctx.dt, traj_bar=tb, cost_bar=zero)
+        return (gx.to(ctx.devs[0]), gu.to(ctx.devs[1]), None, None, None, None) + (None,) * nk
+
+
+def _rollout(model, y0, controls, dt, integrator):
+    keys, params = [], []
+    if torch.is_grad_enabled():
+        if model.engine.has_wgrad:
+            keys, params = grad_params(model)
+        elif any(p.requires_grad for p in model.parameters()):
+            _no_wgrad_warning(model)
+    return _RolloutFn.apply(y0, controls, model, dt, integrator, keys, *params)
 
 
 def _check_integrator(integrator):
@@ -91,21 +115,30 @@ def rollout_trajectory(model, y0, controls, dt, integrator="rk4"):
     if not isinstance(model, _EngineBacked):
         raise TypeError("rollout_trajectory needs an engine-backed model (phnn_mpc_amd.models)")
     with torch.no_grad():
-        traj = _RolloutFn.apply(y0, controls, model, dt, integrator)
+        traj = _rollout(model, y0, controls, dt, integrator)[0]
         energies = _energies(model, traj, controls)
     return traj, energies
 
 
-def rollout_trajectory_differentiable(model, y0, controls, dt, integrator="rk4", return_energies=False):
+def rollout_trajectory_differentiable(model, y0, controls, dt, integrator="rk4", return_energies=False,
+                                      return_derivatives=False):
     """-> trajectory (B,T+1,n) [, energies (B,T+1)]   (src/integrators.py:192-258).
 
-    Differentiable w.r.t. y0 and controls.  With return_energies the reference returns H at the CURRENT state of
-    each step, so energies[:,1] duplicates energies[:,0]; reproduced here.
+    Differentiable w.r.t. y0, the controls AND the model's parameters (pHNN / canonical pHNN): one fused forward
+    launch, and one adjoint + one reduction launch in backward, replace the reference's Python time loop and its
+    autograd graph.  return_derivatives=True (not in the reference's signature) additionally returns
+    dX (B,T,n) = f(x_t,u_t) of every step, differentiable too -- the dX_pred the training loops collect
+    (main.py:116-122).  With return_energies the reference returns H at the CURRENT state of each step, so
+    energies[:,1] duplicates energies[:,0]; reproduced here.
     """
     _check_integrator(integrator)
     if not isinstance(model, _EngineBacked):
         raise TypeError("rollout_trajectory_differentiable needs an engine-backed model (phnn_mpc_amd.models)")
-    traj = _RolloutFn.apply(y0, controls, model, dt, integrator)
+    traj, dX = _rollout(model, y0, controls, dt, integrator)
+    if return_derivatives:
+        if return_energies:
+            raise ValueError("return_derivatives and return_energies are exclusive")
+        return traj, dX
     if not return_energies:
         return traj
     with torch.no_grad():

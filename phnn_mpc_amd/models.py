@@ -59,23 +59,71 @@ def _mlp_from(params, input_dim, output_dim):
                dropout=params["dropout"], layer_norm=params["layer_norm"], bias=params["bias"])
 
 
+def grad_params(owner):
+    """Parameters of an engine-backed module that (a) live in the weight blob and (b) require grad, in blob order:
+    ([state_dict keys], [nn.Parameter]).  Buffers (G_fixed, the canonical J / G) are not parameters."""
+    named = dict(owner.named_parameters())
+    keys = [k for k, _, _ in owner.engine.layout if k in named and named[k].requires_grad]
+    return keys, [named[k] for k in keys]
+
+
+def split_param_grads(engine, grad_theta, keys, device):
+    """gradient blob -> tuple of per-parameter gradients in the order of `keys` (on `device`)."""
+    named = engine.named_grads(grad_theta)
+    return tuple(named[k].to(device) for k in keys)
+
+
+_warned_no_wgrad = set()
+
+
+def _no_wgrad_warning(owner):
+    name = type(owner).__name__
+    if name not in _warned_no_wgrad:
+        _warned_no_wgrad.add(name)
+        import warnings
+        warnings.warn(f"{name}: the engine has no weight-gradient kernels for this model family; backward() leaves "
+                      "its parameters without .grad (gradients w.r.t. inputs are exact)", RuntimeWarning, stacklevel=3)
+
+
 class _ModelFn(torch.autograd.Function):
+    """model(x,u) -> (dx, H) on the engine.  backward: VJP w.r.t. x and u (phnn_model_vjp) and, when parameters
+    require grad, the parameter gradients of the same cotangents (phnn_model_wgrad) -- what autograd does for one
+    model call of the reference (src/pHNN.py:52-100)."""
+
     @staticmethod
-    def forward(ctx, x, u, owner):
+    def forward(ctx, x, u, owner, keys, *params):
         eng = owner.engine
         xd, ud = x.detach().to(eng.device, torch.float32), u.detach().to(eng.device, torch.float32)
         dx, H = eng.forward(xd, ud)
-        ctx.owner, ctx.dev = owner, x.device
+        ctx.owner, ctx.dev, ctx.keys = owner, x.device, keys
+        ctx.pdev = params[0].device if params else None
         ctx.save_for_backward(xd, ud)
-        ctx.mark_non_differentiable(H)
+        ctx.set_materialize_grads(False)  # an unused output arrives as None, not as a tensor of zeros
         return dx.to(x.device), H.to(x.device)
 
     @staticmethod
     def backward(ctx, gdx, gH):
         xd, ud = ctx.saved_tensors
         eng = ctx.owner.engine
-        xb, ub = eng.vjp(xd, ud, gdx.to(eng.device, torch.float32))
-        return xb.to(ctx.dev), ub.to(ctx.dev), None
+        gdx = torch.zeros_like(xd) if gdx is None else gdx.to(eng.device, torch.float32)
+        want_params = bool(ctx.keys) and any(ctx.needs_input_grad[4:])
+        if want_params or (gH is not None and eng.has_wgrad):
+            gth, xb, ub = eng.model_wgrad(xd, ud, gdx, None if gH is None else gH.to(eng.device, torch.float32))
+            pg = split_param_grads(eng, gth, ctx.keys, ctx.pdev) if want_params else (None,) * len(ctx.keys)
+            return (xb.to(ctx.dev), ub.to(ctx.dev), None, None) + pg
+        xb, ub = eng.vjp(xd, ud, gdx)
+        return (xb.to(ctx.dev), ub.to(ctx.dev), None, None) + (None,) * len(ctx.keys)
+
+
+def call_model_fn(owner, x, u):
+    """_ModelFn with the module's trainable parameters as explicit inputs (so backward can hand them gradients)."""
+    keys, params = [], []
+    if torch.is_grad_enabled():
+        if owner.engine.has_wgrad:
+            keys, params = grad_params(owner)
+        elif any(p.requires_grad for p in owner.parameters()):
+            _no_wgrad_warning(owner)
+    return _ModelFn.apply(x, u, owner, keys, *params)
 
 
 class _EngineBacked(nn.Module):
@@ -170,7 +218,7 @@ class pHNN(_EngineBacked):
 
     def forward(self, x, u):
         x, u = self._flatten(x), self._flatten(u)
-        return _ModelFn.apply(x, u, self)
+        return call_model_fn(self, x, u)
 
 
 class CartPoleMassMatrix(nn.Module):
@@ -236,11 +284,20 @@ class pHNN_Canonical(_EngineBacked):
         return R.unsqueeze(0).expand(batch_size, -1, -1)
 
     def forward(self, y, u, return_intermediate=False):
-        if return_intermediate:
-            raise NotImplementedError("return_intermediate=True (diagnostic dict) is not produced by the fused kernel")
+        """-> (dy, H, intermediate | None).  With return_intermediate the reference returns a dict of intermediates
+        (src/pHNN_canonical.py:259-271); the training loop reads 'q_dot_reconstructed' from it
+        (scripts/train_cartpole_phnn_canonical.py:141-146), which IS the first half of dy (q_dot = M^-1 p).  The
+        keys that are views of the outputs or cheap functions of the inputs are provided; 'dH_dz' and 'dz_dt' live
+        only inside the fused kernel and are not returned."""
         y, u = self._flatten(y), self._flatten(u)
-        dy, H = _ModelFn.apply(y, u, self)
-        return dy, H, None
+        dy, H = call_model_fn(self, y, u)
+        if not return_intermediate:
+            return dy, H, None
+        q, qd = y[:, :self.q_dim], y[:, self.q_dim:]
+        p = torch.bmm(self.M_net(q), qd.unsqueeze(-1)).squeeze(-1)
+        inter = {"z": torch.cat([q, p], dim=1), "q": q, "p": p, "q_dot_reconstructed": dy[:, :self.q_dim],
+                 "R": self.get_R_matrix(y.shape[0])}
+        return dy, H, inter
 
     def get_velocity_reconstruction(self, y):
         q, qd = y[:, :self.q_dim], y[:, self.q_dim:]
@@ -281,9 +338,9 @@ class ODEFunc(_EngineBacked):
         action = self.current_action
         if action.shape[0] == 1 and state.shape[0] > 1:
             action = action.expand(state.shape[0], -1)
-        dx, _ = _ModelFn.apply(state, action, self)
+        dx, _ = call_model_fn(self, state, action)
         return dx
 
     def dynamics(self, y, u):
         """model(y,u) -> (dy, H=0) view used by the integrators (no side channel)."""
-        return _ModelFn.apply(self._flatten(y), self._flatten(u), self)
+        return call_model_fn(self, self._flatten(y), self._flatten(u))

@@ -134,3 +134,58 @@ def pack_state_dict(sd, kind=None, state_dim=None, input_dim=None, activation="t
         raise ValueError(f"unknown model kind {kind}")
     blob = np.ascontiguousarray(np.concatenate(parts).astype(np.float32))
     return d, blob
+
+
+def blob_layout(sd, kind=None):
+    """[(state_dict key, offset, shape)] of every tensor inside the float32 weight blob of pack_state_dict, in blob
+    order.  The gradient blob the weight-gradient kernels return has the same layout; entries that are buffers of
+    the reference modules (G_fixed; the canonical model's G) or constants to autograd (M_net.*) stay zero there."""
+    sd = unwrap_checkpoint(sd)
+    if kind is None:
+        kind = detect_kind(sd)
+    out, off = [], 0
+
+    def add(key, shape):
+        nonlocal off
+        cnt = 1
+        for d in shape:
+            cnt *= int(d)
+        out.append((key, off, tuple(int(d) for d in shape)))
+        off += cnt
+
+    def add_mlp(prefix):
+        idx = sorted({int(k[len(prefix):].split(".")[0]) for k in sd if k.startswith(prefix) and k.endswith(".weight")})
+        for i in idx:
+            add(f"{prefix}{i}.weight", _np(sd[f"{prefix}{i}.weight"]).shape)
+            add(f"{prefix}{i}.bias", _np(sd[f"{prefix}{i}.bias"]).shape)
+
+    if kind == _capi.MODEL_PHNN:
+        add("J", _np(sd["J"]).shape)
+        if "G_fixed" in sd:
+            add("G_fixed", _np(sd["G_fixed"]).shape)
+        add_mlp("R_net.net.")
+        add_mlp("H_net.net.")
+        if "G_fixed" not in sd:
+            add_mlp("G_net.net.")
+    elif kind == _capi.MODEL_CANONICAL:
+        add("R_diag_raw", _np(sd["R_diag_raw"]).shape)
+        add("G", _np(sd["G"]).shape)
+        for k in ("M_net.log_a", "M_net.b", "M_net.log_c"):
+            add(k, ())
+        add_mlp("H_net.net.")
+    elif kind == _capi.MODEL_ODEFUNC:
+        add_mlp("network.")
+    else:
+        raise ValueError(f"unknown model kind {kind}")
+    return out
+
+
+def unpack_grad_blob(sd, blob, kind=None, layout=None):
+    """gradient blob (P,) -> {state_dict key: array of the parameter's shape} (numpy or torch, views of `blob`)."""
+    res = {}
+    for key, off, shape in (layout if layout is not None else blob_layout(sd, kind)):
+        cnt = 1
+        for d in shape:
+            cnt *= d
+        res[key] = blob[off:off + cnt].reshape(shape)
+    return res

@@ -15,6 +15,43 @@ class OracleEngine:
         self.n, self.m = self.m_.n, self.m_.m
         self.device = torch.device("cpu")
         self.np_dtype = self.m_.dtype
+        from phnn_mpc_amd import weights
+        self.layout = weights.blob_layout(state_dict, kind=self.m_.desc.kind)
+        self.has_wgrad = self.m_.desc.kind != _capi.MODEL_ODEFUNC  # mirrors the product: pHNN and canonical only
+
+    def rollout_trajectory(self, x0, u, integrator="euler", dt=0.02, want_dx=False):
+        r = self.m_.rollout_wgrad(np.asarray(x0), np.asarray(u), integrator, dt)
+        return (self._out(r["traj"]), self._out(r["dX"])) if want_dx else self._out(r["traj"])
+
+    def rollout_wgrad(self, x0, u, traj, integrator="euler", dt=0.02, traj_bar=None, dx_bar=None, grad_theta=None,
+                      accumulate=False):
+        r = self.m_.rollout_wgrad(np.asarray(x0), np.asarray(u), integrator, dt,
+                                  None if traj_bar is None else np.asarray(traj_bar),
+                                  None if dx_bar is None else np.asarray(dx_bar))
+        return self._out(r["grad_theta"]), self._out(r["grad_u"]), self._out(r["grad_x0"])
+
+    def model_wgrad(self, x, u, lam, Hbar=None, grad_theta=None, accumulate=False):
+        g = self.m_.wgrad(np.asarray(x), np.asarray(u), np.asarray(lam), None if Hbar is None else np.asarray(Hbar))
+        xb, ub = self.m_.vjp(np.asarray(x), np.asarray(u), np.asarray(lam))
+        if Hbar is not None:  # cotangent on H adds Hbar dH/dx: dH/dx = VJP of H, taken by finite structure of the oracle
+            xb = xb + np.asarray(Hbar, self.np_dtype)[:, None] * self._dH(np.asarray(x), np.asarray(u))
+        return self._out(g), self._out(xb), self._out(ub)
+
+    def _dH(self, x, u):
+        """dH/dx by central differences of the oracle's H in float64 (test infrastructure; only the energy-anchor
+        path needs it and there the input gradient is not consumed)."""
+        eps = 1e-6
+        out = np.zeros((x.shape[0], self.n))
+        for i in range(self.n):
+            xp, xm = np.array(x, np.float64), np.array(x, np.float64)
+            xp[:, i] += eps
+            xm[:, i] -= eps
+            out[:, i] = (self.m_.forward(xp, u)[1] - self.m_.forward(xm, u)[1]) / (2 * eps)
+        return out.astype(self.np_dtype)
+
+    def named_grads(self, grad_theta):
+        from phnn_mpc_amd import weights
+        return weights.unpack_grad_blob(None, grad_theta, layout=self.layout)
 
     def _out(self, a):
         return torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))

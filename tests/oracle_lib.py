@@ -36,6 +36,9 @@ def lib():
             getattr(_lib, f"oracle_rollout_vjp_{suf}").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
                                                                    C.POINTER(_capi.Cost), C.c_int, C.c_double,
                                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            getattr(_lib, f"oracle_wgrad_{suf}").argtypes = [C.c_void_p] * 5 + [C.c_long, C.c_void_p]
+            getattr(_lib, f"oracle_rollout_wgrad_{suf}").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int,
+                                                                     C.c_int, C.c_double] + [C.c_void_p] * 7
             getattr(_lib, f"oracle_adam_{suf}").argtypes = [C.c_void_p] * 4 + [C.c_long] + [C.c_double] * 4 + [C.c_int]
     return _lib
 
@@ -106,6 +109,31 @@ class OracleModel:
                                                          float(dt), _ptr(tb), _ptr(cb), _ptr(gu), _ptr(gx))
         return gu, gx
 
+    def wgrad(self, x, u, lam, Hbar=None):
+        """Parameter gradient blob (P,) of sum_p lam_p . f(x_p,u_p) + Hbar_p H(x_p)."""
+        x, u, lam = self._a(x, (-1, self.n)), self._a(u, (-1, self.m)), self._a(lam, (-1, self.n))
+        hb = None if Hbar is None else self._a(Hbar, (-1,))
+        g = np.zeros(self.blob.size, self.dtype)
+        getattr(lib(), f"oracle_wgrad_{self.suf}")(self.h, _ptr(x), _ptr(u), _ptr(lam), _ptr(hb), x.shape[0], _ptr(g))
+        return g
+
+    def rollout_wgrad(self, x0, U, integrator, dt, traj_bar=None, dx_bar=None):
+        """Rollout (no clamp, no cost) + reverse pass with cotangents on the trajectory and on the per-step
+        derivatives -> dict(traj, dX, grad_theta (P,), grad_u, grad_x0)."""
+        x0 = self._a(x0, (-1, self.n))
+        B = x0.shape[0]
+        U = self._a(U).reshape(B, -1, self.m)
+        H = U.shape[1]
+        tb = None if traj_bar is None else self._a(traj_bar, (B, H + 1, self.n))
+        db = None if dx_bar is None else self._a(dx_bar, (B, H, self.n))
+        traj, dX = np.empty((B, H + 1, self.n), self.dtype), np.empty((B, H, self.n), self.dtype)
+        g = np.zeros(self.blob.size, self.dtype)
+        gu, gx = np.empty((B, H, self.m), self.dtype), np.empty((B, self.n), self.dtype)
+        integ = _capi.INTEGRATORS[integrator] if isinstance(integrator, str) else int(integrator)
+        getattr(lib(), f"oracle_rollout_wgrad_{self.suf}")(self.h, _ptr(x0), _ptr(U), B, H, integ, float(dt), _ptr(tb),
+                                                           _ptr(db), _ptr(traj), _ptr(dX), _ptr(g), _ptr(gu), _ptr(gx))
+        return {"traj": traj, "dX": dX, "grad_theta": g, "grad_u": gu, "grad_x0": gx}
+
     def adam(self, p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
         """In-place Adam step on arrays of self.dtype."""
         for a in (p, g, m, v):
@@ -115,6 +143,11 @@ class OracleModel:
 
 def load_weights(name):
     with np.load(os.path.join(GOLDEN, f"weights_{name}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def load_wgrad_golden():
+    with np.load(os.path.join(GOLDEN, "golden_wgrad.npz")) as z:
         return {k: z[k] for k in z.files}
 
 

@@ -194,13 +194,19 @@ def test_device_restored_after_calls(torch):
 
 # ----------------------------------------------------------------------------- the plant on the device (row f3)
 def test_plant_kernel_matches_reference_simulator_g11(torch, ctl):
-    """k_plant_step against the reference simulator's own trajectory (G11, float64).  Every operation is IEEE
-    double in the reference's order; the only thing that can differ from numpy is the last bit of the device's
-    double-precision sin/cos, hence 1e-13 absolute instead of bitwise (the host restatement uses the same bound)."""
+    """k_plant_step against the reference simulator (float64).  The C-ABI takes the force as float32 -- what the
+    controllers return -- so (a) plant 2 of G11, whose forces are float32-exact (14.0), is compared with the
+    reference's own trajectory directly, and (b) all three plants are compared with the host restatement
+    BatchedCartPole (pinned to G11 in tests/test_host_logic.py) fed the same float32-rounded forces.  Every
+    operation is IEEE double in the reference's order; only the last bit of the device's double-precision sin/cos
+    can differ from numpy's, hence 1e-13 absolute instead of bitwise."""
     from phnn_mpc_amd import _capi
+    from phnn_mpc_amd.closed_loop import BatchedCartPole
     from phnn_mpc_amd.engine import RolloutEngine
     eng = RolloutEngine(ol.load_weights("phnn_cartpole"))
-    init, forces = ctl["plant_init"], ctl["plant_forces"]
+    init = ctl["plant_init"]
+    forces = ctl["plant_forces"].astype(np.float32)
+    assert np.array_equal(forces[:, 2].astype(np.float64), ctl["plant_forces"][:, 2])
     B, T = init.shape[0], forces.shape[0]
     state = torch.tensor(init, dtype=torch.float64, device="cuda")
     x32 = torch.empty(B, 4, dtype=torch.float32, device="cuda")
@@ -208,15 +214,21 @@ def test_plant_kernel_matches_reference_simulator_g11(torch, ctl):
     logs = torch.zeros(T + 1, B, 4, dtype=torch.float64, device="cuda")
     logc = torch.zeros(T, B, dtype=torch.float32, device="cuda")
     plant = _capi.Plant.default(0.02)
+    host = BatchedCartPole(0.02)
+    host.reset(init)
+    host_done = np.full(B, -1)
     for t in range(T):
-        a = torch.tensor(np.asarray(forces[t], dtype=np.float32).reshape(B), device="cuda")
+        a = torch.tensor(forces[t].reshape(B), device="cuda")
         eng.plant_step(plant, state, a, 1, state_f32=x32, done_step=done_step, step=t, log_states=logs, log_controls=logc)
-        assert np.allclose(npy(state), ctl["plant_states"][t + 1], rtol=0, atol=1e-13)
-        assert np.array_equal(npy(x32), ctl["plant_states"][t + 1].astype(np.float32).astype(np.float64)) or \
-            np.allclose(npy(x32), ctl["plant_states"][t + 1], rtol=1e-7, atol=1e-30)
-    assert np.allclose(npy(logs)[1:], ctl["plant_states"][1:], rtol=0, atol=1e-13)
-    first_done = np.array([np.argmax(ctl["plant_done"][:, b]) if ctl["plant_done"][:, b].any() else -1 for b in range(B)])
-    assert np.array_equal(done_step.cpu().numpy(), first_done)
+        hs, hd = host.step(forces[t].astype(np.float64))
+        host_done[(host_done < 0) & hd] = t
+        assert np.allclose(npy(state), hs, rtol=0, atol=1e-13)
+        assert np.allclose(npy(state)[2], ctl["plant_states"][t + 1, 2], rtol=0, atol=1e-13)
+        assert np.allclose(npy(x32), hs.astype(np.float32).astype(np.float64), rtol=2e-7, atol=1e-30)
+    assert np.allclose(npy(logs)[1:, 2], ctl["plant_states"][1:, 2], rtol=0, atol=1e-13)
+    assert np.array_equal(logc.cpu().numpy(), forces)
+    assert np.array_equal(done_step.cpu().numpy(), host_done)
+    assert done_step[2].item() == int(np.argmax(ctl["plant_done"][:, 2]))
 
 
 def test_device_closed_loop_equals_host_loop(torch):
@@ -280,3 +292,31 @@ def test_device_closed_loop_300_steps_4096_plants(torch):
     print("device closed loop: %d plants x %d control steps (H=20, 30 Adam iterations) in %.2f s = %.0f controls/s; "
           "%d plants terminated, %d meet the stability criterion (seed-0 weights, untrained)" % (
               B, T, el, B * T / el, int((ds >= 0).sum()), int(rep["stable"].sum())))
+
+
+@pytest.mark.parametrize("name", ["phnn_cartpole", "canonical_cartpole"])
+def test_full_size_bitwise_repeatable(torch, name):
+    """The bench workload (B=65536, H=50, two waves per SIMD) run repeatedly on the same inputs: K1 and K2, stash and
+    recompute mode, must be bitwise repeatable.  Regression test: the adjoint kernels built with LLVM's max-ILP
+    scheduling strategy (round 1's last +2 %) were NOT -- a few hundred rollouts per launch, mostly in the second wave
+    of a SIMD, differed by 2e-7 ... 4e-2 of their largest gradient entry from run to run, which small batches (one
+    wave per SIMD) never show."""
+    from phnn_mpc_amd.engine import RolloutEngine
+    g, w = ol.load_golden("phnn_cartpole"), ol.load_weights(name)
+    eng = RolloutEngine(w)
+    rng = np.random.default_rng(1234)
+    B, H = 65536, 50
+    x0 = torch.tensor((rng.uniform(-1, 1, size=(B, 4)) * [1.0, 0.3, 0.5, 0.5]).astype(np.float32), device="cuda")
+    U = torch.tensor(rng.uniform(-5, 5, size=(B, H, 1)).astype(np.float32), device="cuda")
+    cost = ol.cost_from_golden(g)
+    assert eng.kernel_info(B)["rollouts_per_workgroup"] == 128
+    for stash in (True, False):
+        eng.use_stash = stash
+        ws = {}
+        c0, g0 = [t.clone() for t in eng.rollout_cost_grad(x0, U, cost, "euler", 0.02, workspace=ws)]
+        for _ in range(6):
+            c, gu = eng.rollout_cost_grad(x0, U, cost, "euler", 0.02, workspace=ws)
+            assert torch.equal(c, c0)
+            nbad = int((gu != g0).any(dim=2).any(dim=1).sum())
+            assert nbad == 0, (name, "stash" if stash else "recompute", nbad)
+    eng.use_stash = True

@@ -1,0 +1,255 @@
+"""GPU parity of the training-side path: gradients w.r.t. the MODEL PARAMETERS.
+
+The weight-gradient kernels (k_rollout_grad / k_model_vjp built with the record flag + k_wgrad_reduce), called through
+the C-ABI (phnn_rollout_trajectory, phnn_rollout_wgrad, phnn_model_wgrad) and through the drop-in autograd surface,
+against (a) the reference's own gradients (golden sets G14-G16, tests/golden/make_golden_wgrad.py) and (b) the float64
+CPU oracle on seeded inputs.
+
+Stated tolerance: every parameter tensor within 1e-4 of its largest reference gradient entry
+(|ours - ref| <= 1e-4 max|ref|); losses rtol 1e-5; trajectories as in test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs", "cartpole_mpc.yaml")
+CFG_PEND = os.path.join(ROOT, "configs", "pendulum.yaml")
+WG_MODELS = ["phnn_cartpole", "canonical_cartpole", "phnn_pendulum"]
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def wg():
+    return ol.load_wgrad_golden()
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def check_named(named, ref_named, what, tol=TOL):
+    worst = 0.0
+    for name, ref in ref_named.items():
+        ref = np.asarray(ref, np.float64)
+        ours = np.asarray(named[name], np.float64).reshape(ref.shape)
+        mx = np.abs(ref).max()
+        if mx == 0:
+            assert np.all(ours == 0), (what, name)
+            continue
+        err = np.abs(ours - ref).max() / mx
+        worst = max(worst, err)
+        assert err <= tol, (what, name, err)
+    return worst
+
+
+def golden_named(wg, prefix, tag="f64"):
+    return {k[len(prefix) + 2:-len(tag) - 1]: wg[k] for k in wg if k.startswith(prefix + "g.") and k.endswith("_" + tag)}
+
+
+def oracle_named(w, blob):
+    from phnn_mpc_amd import weights
+    named = weights.unpack_grad_blob(w, blob)
+    return {k: v for k, v in named.items()}
+
+
+@pytest.mark.parametrize("name", WG_MODELS)
+def test_point_wgrad_vs_reference_g14(torch, wg, name):
+    from phnn_mpc_amd.engine import RolloutEngine
+    w = ol.load_weights(name)
+    eng = RolloutEngine(w)
+    assert eng.has_wgrad
+    pre = f"{name}/pt_"
+    g, xb, ub = eng.model_wgrad(wg[pre + "x"], wg[pre + "u"], wg[pre + "lam"], wg[pre + "Hbar"])
+    worst = check_named({k: npy(v) for k, v in eng.named_grads(g).items()}, golden_named(wg, pre), name)
+    # input cotangents of the same call: lam on dx plus Hbar on H
+    m64 = ol.OracleModel(w, "f64")
+    rxb, rub = m64.vjp(wg[pre + "x"], wg[pre + "u"], wg[pre + "lam"])
+    eps = 1e-6
+    dH = np.stack([(m64.forward(wg[pre + "x"] + eps * np.eye(eng.n)[i], wg[pre + "u"])[1]
+                    - m64.forward(wg[pre + "x"] - eps * np.eye(eng.n)[i], wg[pre + "u"])[1]) / (2 * eps)
+                   for i in range(eng.n)], axis=1)
+    rxb = rxb + wg[pre + "Hbar"][:, None] * dH
+    assert np.abs(npy(xb) - rxb).max() <= 3e-5 * np.abs(rxb).max()
+    assert np.abs(npy(ub) - rub).max() <= 3e-5 * max(np.abs(rub).max(), 1e-30)
+    # buffers / autograd constants stay exactly zero
+    named = eng.named_grads(g)
+    for k in ("G_fixed", "G", "M_net.log_a", "M_net.b", "M_net.log_c"):
+        if k in named:
+            assert bool((named[k] == 0).all())
+    print(f"{name}: point wgrad worst tensor error {worst:.2e} of max|grad|")
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+@pytest.mark.parametrize("name", WG_MODELS)
+def test_rollout_wgrad_vs_reference_g16(torch, wg, name, integ):
+    from phnn_mpc_amd.engine import RolloutEngine
+    w = ol.load_weights(name)
+    eng = RolloutEngine(w)
+    pre = f"{name}/rw_"
+    dt = float(wg[pre + "dt"])
+    traj, dX = eng.rollout_trajectory(wg[pre + "x0"], wg[pre + "U"], integ, dt, want_dx=True)
+    atol = 5e-5 if "pendulum" in name else 1e-5
+    assert np.allclose(npy(traj), wg[f"{pre}{integ}_traj_f64"], rtol=1e-5, atol=atol)
+    assert np.allclose(npy(dX), wg[f"{pre}{integ}_dX_f64"], rtol=2e-5, atol=2e-5 * np.abs(wg[f"{pre}{integ}_dX_f64"]).max())
+    g, gu, gx = eng.rollout_wgrad(wg[pre + "x0"], wg[pre + "U"], traj, integ, dt, traj_bar=wg[pre + "traj_bar"],
+                                  dx_bar=wg[pre + "dx_bar"])
+    worst = check_named({k: npy(v) for k, v in eng.named_grads(g).items()}, golden_named(wg, f"{pre}{integ}_"), (name, integ))
+    rgu, rgx = wg[f"{pre}{integ}_gu_f64"], wg[f"{pre}{integ}_gx0_f64"]
+    assert np.abs(npy(gu) - rgu).max() <= TOL * np.abs(rgu).max()
+    assert np.abs(npy(gx) - rgx).max() <= TOL * np.abs(rgx).max()
+    print(f"{name} {integ}: rollout wgrad worst tensor error {worst:.2e} of max|grad|")
+
+
+def _load(cls, cfg, name, torch):
+    m = cls(cfg)
+    m.load_state_dict({k: torch.tensor(v) for k, v in ol.load_weights(name).items()})
+    return m
+
+
+def _named_param_grads(model):
+    return {k: npy(p.grad) if p.grad is not None else np.zeros(tuple(p.shape)) for k, p in model.named_parameters()}
+
+
+def test_training_steps_vs_reference_g15(torch, wg):
+    """One optimisation step of each of the reference's three training loops through the drop-in API on the GPU:
+    loss value and every parameter's gradient against what the reference itself computed."""
+    from phnn_mpc_amd.coordinate_transforms import split_state
+    from phnn_mpc_amd.integrators import rollout_trajectory_differentiable
+    from phnn_mpc_amd.models import pHNN, pHNN_Canonical
+    loss_fn = torch.nn.MSELoss()
+    # (a) scripts/train_cartpole_phnn.py:112-178
+    model = _load(pHNN, CFG, "phnn_cartpole", torch)
+    x_batch, u_batch = torch.tensor(wg["tr_cart_x"]), torch.tensor(wg["tr_cart_u"])
+    X_pred = rollout_trajectory_differentiable(model, x_batch[:, 0, :], u_batch[:, :-1, :], 0.02, "euler")
+    l_pos = loss_fn(X_pred[:, :, 0], x_batch[:, :, 0])
+    l_theta = torch.mean(1 - torch.cos(X_pred[:, :, 1] - x_batch[:, :, 1]))
+    l_vel = loss_fn(X_pred[:, :, 2:], x_batch[:, :, 2:])
+    _, H_zero = model(torch.zeros(1, 4), torch.zeros(1, 1))
+    loss = 1.0 * l_pos + 1.0 * l_theta + 1.0 * l_vel + 0.01 * torch.mean(H_zero ** 2)
+    loss.backward()
+    assert abs(loss.item() / float(wg["phnn_cartpole/tr_loss_f64"]) - 1) < 1e-5
+    wa = check_named(_named_param_grads(model), golden_named(wg, "phnn_cartpole/tr_"), "train_cartpole_phnn")
+    # (b) main.py:93-148, pendulum pHNN with a learned G: losses on X_pred and dX_pred
+    pend = _load(pHNN, CFG_PEND, "phnn_pendulum", torch)
+    x_batch, u_batch, dx_batch = (torch.tensor(wg[k]) for k in ("tr_pend_x", "tr_pend_u", "tr_pend_dx"))
+    X_pred, dX_pred = rollout_trajectory_differentiable(pend, x_batch[:, 0, :], u_batch[:, :-1, :], 0.05, "euler",
+                                                        return_derivatives=True)
+    loss = loss_fn(X_pred, x_batch) + loss_fn(dX_pred, dx_batch[:, 0:-1, :])
+    loss.backward()
+    assert abs(loss.item() / float(wg["phnn_pendulum/tr_loss_f64"]) - 1) < 1e-5
+    wb = check_named(_named_param_grads(pend), golden_named(wg, "phnn_pendulum/tr_"), "main.py")
+    # (c) scripts/train_cartpole_phnn_canonical.py:83-196: the reference's loop as is (a model call per step)
+    can = _load(pHNN_Canonical, CFG, "canonical_cartpole", torch)
+    x_batch, u_batch = torch.tensor(wg["tr_cart_x"]), torch.tensor(wg["tr_cart_u"])
+    y_pred, vel_err = [x_batch[:, 0, :]], []
+    for t in range(x_batch.shape[1] - 1):
+        dy, _, inter = can(y_pred[-1], u_batch[:, t, :], return_intermediate=True)
+        y_pred.append(y_pred[-1] + 0.02 * dy)
+        _, qd_true = split_state(x_batch[:, t, :])
+        vel_err.append(torch.sum((inter["q_dot_reconstructed"] - qd_true) ** 2, dim=1).mean())
+    y_pred = torch.stack(y_pred, dim=1)
+    l_pos = torch.mean((y_pred[:, :, 0] - x_batch[:, :, 0]) ** 2) + torch.mean(1 - torch.cos(y_pred[:, :, 1] - x_batch[:, :, 1]))
+    l_vel = torch.mean(torch.stack(vel_err))
+    (1.0 * l_pos + 0.5 * l_vel).backward()
+    assert abs(l_pos.item() / float(wg["canonical_cartpole/tr_loss_position_f64"]) - 1) < 1e-5
+    assert abs(l_vel.item() / float(wg["canonical_cartpole/tr_loss_velocity_f64"]) - 1) < 1e-5
+    wc = check_named(_named_param_grads(can), golden_named(wg, "canonical_cartpole/tr_"), "train_canonical")
+    # the same canonical loss through the fused path (one rollout launch, dX carries q_dot_reconstructed)
+    can2 = _load(pHNN_Canonical, CFG, "canonical_cartpole", torch)
+    Y, dY = rollout_trajectory_differentiable(can2, x_batch[:, 0, :], u_batch[:, :-1, :], 0.02, "euler", return_derivatives=True)
+    l_pos2 = torch.mean((Y[:, :, 0] - x_batch[:, :, 0]) ** 2) + torch.mean(1 - torch.cos(Y[:, :, 1] - x_batch[:, :, 1]))
+    l_vel2 = torch.mean(torch.sum((dY[:, :, :2] - x_batch[:, :-1, 2:]) ** 2, dim=2).mean(dim=0))
+    (1.0 * l_pos2 + 0.5 * l_vel2).backward()
+    wd = check_named(_named_param_grads(can2), golden_named(wg, "canonical_cartpole/tr_"), "train_canonical fused")
+    print("training steps: worst tensor error / max|grad|: phnn %.2e, pendulum %.2e, canonical %.2e (fused %.2e)" % (wa, wb, wc, wd))
+
+
+@pytest.mark.parametrize("name", WG_MODELS + ["phnn_cartpole_odd"])
+def test_rollout_wgrad_vs_oracle_ragged(torch, name):
+    """Seeded batches that do not fill 16-rollout tiles or workgroups (B = 5, 37, 300), against the float64 oracle;
+    accumulate flag; bitwise repeatability; zero-padded widths (phnn_cartpole_odd: H_mlp [96,80], R_mlp [48])."""
+    from phnn_mpc_amd.engine import RolloutEngine
+    w = ol.load_weights(name)
+    eng, m64 = RolloutEngine(w), ol.OracleModel(w, "f64")
+    n = eng.n
+    rng = np.random.default_rng(77)
+    dt = 0.05 if n == 2 else 0.02
+    for B, H, integ in ((5, 7, "euler"), (37, 11, "rk4"), (300, 16, "euler")):
+        x0 = (rng.uniform(-1, 1, size=(B, n)) * ([1.0, 0.3, 0.5, 0.5][:n] if n == 4 else [1.5, 0.8])).astype(np.float32)
+        U = rng.uniform(-3, 3, size=(B, H, 1)).astype(np.float32)
+        tb = rng.normal(size=(B, H + 1, n)).astype(np.float32)
+        db = rng.normal(size=(B, H, n)).astype(np.float32)
+        ref = m64.rollout_wgrad(x0, U, integ, dt, tb, db)
+        traj = eng.rollout_trajectory(x0, U, integ, dt)
+        g, gu, gx = eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb, dx_bar=db)
+        g1 = g.clone()
+        check_named({k: npy(v) for k, v in eng.named_grads(g).items()}, oracle_named(w, ref["grad_theta"]), (name, B, H, integ))
+        assert np.abs(npy(gu) - ref["grad_u"]).max() <= TOL * np.abs(ref["grad_u"]).max()
+        assert np.abs(npy(gx) - ref["grad_x0"]).max() <= TOL * np.abs(ref["grad_x0"]).max()
+        g2, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb, dx_bar=db)
+        assert torch.equal(g1, g2)  # fixed summation order: bitwise repeatable
+        acc = g1.clone()
+        eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb, dx_bar=db, grad_theta=acc, accumulate=True)
+        assert torch.allclose(acc, 2 * g1, rtol=1e-6, atol=0)
+    # only one of the two cotangents
+    g_t, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb)
+    g_d, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, dx_bar=db)
+    assert torch.allclose(g_t + g_d, g1, rtol=0, atol=2e-5 * float(g1.abs().max()))
+
+
+def test_wgrad_other_matmul_modes_and_unsupported(torch, wg):
+    """All-f32 products give the same gradients within tolerance; ODEFunc has no weight-gradient kernels and says so."""
+    from phnn_mpc_amd.engine import PhnnError, RolloutEngine
+    w = ol.load_weights("phnn_cartpole")
+    pre = "phnn_cartpole/pt_"
+    for mode in ("f32", "f16x2"):
+        eng = RolloutEngine(w, matmul=mode)
+        g, _, _ = eng.model_wgrad(wg[pre + "x"], wg[pre + "u"], wg[pre + "lam"], wg[pre + "Hbar"])
+        check_named({k: npy(v) for k, v in eng.named_grads(g).items()}, golden_named(wg, pre), mode)
+    ode = RolloutEngine(ol.load_weights("odefunc_pendulum"))
+    assert not ode.has_wgrad
+    with pytest.raises(PhnnError, match="weight-gradient"):
+        ode.model_wgrad(np.zeros((4, 2), np.float32), np.zeros((4, 1), np.float32), np.zeros((4, 2), np.float32))
+
+
+def test_training_loop_descends_and_weights_refresh(torch, wg):
+    """A few Adam steps on the model parameters through the fused rollout: the engine re-packs the weights after every
+    optimizer step (no stale weights) and the loss goes down; the same steps on the float64 oracle engine agree."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_engine import OracleEngine
+    from phnn_mpc_amd.integrators import rollout_trajectory_differentiable
+    from phnn_mpc_amd.models import pHNN
+    x_batch, u_batch = torch.tensor(wg["tr_cart_x"]), torch.tensor(wg["tr_cart_u"])
+    losses = {}
+    for kind in ("gpu", "oracle"):
+        model = _load(pHNN, CFG, "phnn_cartpole", torch)
+        if kind == "oracle":
+            model.set_engine(OracleEngine(ol.load_weights("phnn_cartpole"), "f64"))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        hist = []
+        for it in range(4):
+            if kind == "oracle":  # the oracle engine is externally managed: rebuild it from the current parameters
+                model.set_engine(OracleEngine({k: v.detach().numpy() for k, v in model.state_dict().items()}, "f64"))
+            opt.zero_grad()
+            X = rollout_trajectory_differentiable(model, x_batch[:, 0, :], u_batch[:, :-1, :], 0.02, "euler")
+            loss = torch.mean((X - x_batch) ** 2)
+            loss.backward()
+            opt.step()
+            hist.append(loss.item())
+        losses[kind] = hist
+    assert losses["gpu"][-1] < losses["gpu"][0]
+    assert np.allclose(losses["gpu"], losses["oracle"], rtol=2e-4), (losses["gpu"], losses["oracle"])

@@ -331,3 +331,85 @@ def test_lbfgs_branch_matches_reference_g13(ctl):
     assert u0.shape == (1,) and abs(u0[0] - ctl["lbfgs_u0"][0]) < 5e-4 * max(1.0, abs(ctl["lbfgs_u0"][0])), (u0, ctl["lbfgs_u0"])
     with pytest.raises(NotImplementedError):
         c.compute_control_batch(ctl["mpc_x0"][None])
+
+
+# ----------------------------------------------------------------------------- training side (row f4), host logic on the oracle
+def _named_param_grads(model):
+    return {k: (p.grad.detach().numpy().astype(np.float64) if p.grad is not None else np.zeros(tuple(p.shape)))
+            for k, p in model.named_parameters()}
+
+
+def _check_named(named, wg, prefix, tag, rtol):
+    keys = [k for k in wg if k.startswith(prefix + "g.") and k.endswith("_" + tag)]
+    assert keys
+    for k in keys:
+        name = k[len(prefix) + 2:-len(tag) - 1]
+        ref = np.asarray(wg[k], np.float64)
+        mx = np.abs(ref).max()
+        ours = named[name].reshape(ref.shape)
+        assert np.abs(ours - ref).max() <= rtol * max(mx, 1e-30), (name, np.abs(ours - ref).max(), mx)
+
+
+def test_training_step_phnn_cartpole_g15():
+    """One optimisation step's loss and parameter gradients of scripts/train_cartpole_phnn.py:112-178, written against
+    the drop-in API: the fused differentiable rollout for X_pred, a model call for the energy anchor H(0)^2.  The
+    engine is the float64 oracle here (host logic + autograd plumbing); the GPU twin is tests/test_gpu_wgrad.py."""
+    from phnn_mpc_amd.integrators import rollout_trajectory_differentiable
+    wg = ol.load_wgrad_golden()
+    w = ol.load_weights("phnn_cartpole")
+    model = pHNN(CFG)
+    model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    model.set_engine(OracleEngine(w, "f64"))
+    x_batch, u_batch = torch.tensor(wg["tr_cart_x"]), torch.tensor(wg["tr_cart_u"])
+    loss_fn = torch.nn.MSELoss()
+    X_pred = rollout_trajectory_differentiable(model, x_batch[:, 0, :], u_batch[:, :-1, :], 0.02, "euler")
+    l_pos = loss_fn(X_pred[:, :, 0], x_batch[:, :, 0])
+    l_theta = torch.mean(1 - torch.cos(X_pred[:, :, 1] - x_batch[:, :, 1]))
+    l_vel = loss_fn(X_pred[:, :, 2:], x_batch[:, :, 2:])
+    _, H_zero = model(torch.zeros(1, 4), torch.zeros(1, 1))
+    loss = 1.0 * l_pos + 1.0 * l_theta + 1.0 * l_vel + 0.01 * torch.mean(H_zero ** 2)
+    loss.backward()
+    assert abs(loss.item() / float(wg["phnn_cartpole/tr_loss_f64"]) - 1) < 1e-6  # float32 tensors around a float64 engine
+    assert np.allclose(X_pred.detach().numpy(), wg["phnn_cartpole/tr_X_f64"], atol=2e-6)
+    _check_named(_named_param_grads(model), wg, "phnn_cartpole/tr_", "f64", 2e-6)
+
+
+def test_training_step_pendulum_and_canonical_g15():
+    """main.py:93-148 (loss on X_pred and on dX_pred; pendulum pHNN with a learned G) and
+    scripts/train_cartpole_phnn_canonical.py:83-196 (per-step model calls with return_intermediate=True, manual
+    Euler -- the reference's loop as is, every model call one engine call) on the oracle engine."""
+    from phnn_mpc_amd.integrators import rollout_trajectory_differentiable
+    from phnn_mpc_amd.coordinate_transforms import split_state
+    wg = ol.load_wgrad_golden()
+    w = ol.load_weights("phnn_pendulum")
+    model = pHNN(CFG_PEND)
+    model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    model.set_engine(OracleEngine(w, "f64"))
+    x_batch, u_batch, dx_batch = (torch.tensor(wg[k]) for k in ("tr_pend_x", "tr_pend_u", "tr_pend_dx"))
+    loss_fn = torch.nn.MSELoss()
+    X_pred, dX_pred = rollout_trajectory_differentiable(model, x_batch[:, 0, :], u_batch[:, :-1, :], 0.05, "euler",
+                                                        return_derivatives=True)
+    loss = loss_fn(X_pred, x_batch) + loss_fn(dX_pred, dx_batch[:, 0:-1, :])
+    loss.backward()
+    assert abs(loss.item() / float(wg["phnn_pendulum/tr_loss_f64"]) - 1) < 1e-6
+    _check_named(_named_param_grads(model), wg, "phnn_pendulum/tr_", "f64", 2e-6)
+    # canonical: the reference's own loop shape (compute_integrated_loss), model call per step
+    w = ol.load_weights("canonical_cartpole")
+    can = pHNN_Canonical(CFG)
+    can.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    can.set_engine(OracleEngine(w, "f64"))
+    x_batch, u_batch = torch.tensor(wg["tr_cart_x"]), torch.tensor(wg["tr_cart_u"])
+    y_pred, vel_err = [x_batch[:, 0, :]], []
+    for t in range(x_batch.shape[1] - 1):
+        dy, _, inter = can(y_pred[-1], u_batch[:, t, :], return_intermediate=True)
+        y_pred.append(y_pred[-1] + 0.02 * dy)
+        _, qd_true = split_state(x_batch[:, t, :])
+        vel_err.append(torch.sum((inter["q_dot_reconstructed"] - qd_true) ** 2, dim=1).mean())
+    y_pred = torch.stack(y_pred, dim=1)
+    l_pos = torch.mean((y_pred[:, :, 0] - x_batch[:, :, 0]) ** 2) + torch.mean(1 - torch.cos(y_pred[:, :, 1] - x_batch[:, :, 1]))
+    l_vel = torch.mean(torch.stack(vel_err))
+    loss = 1.0 * l_pos + 0.5 * l_vel
+    loss.backward()
+    assert abs(l_pos.item() / float(wg["canonical_cartpole/tr_loss_position_f64"]) - 1) < 1e-5
+    assert abs(l_vel.item() / float(wg["canonical_cartpole/tr_loss_velocity_f64"]) - 1) < 1e-5
+    _check_named(_named_param_grads(can), wg, "canonical_cartpole/tr_", "f64", 5e-6)

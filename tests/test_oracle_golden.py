@@ -145,3 +145,58 @@ def test_torch_restatement_matches_golden():
         # summation order of the cost differs from the reference's Python loops: 1e-9, not bitwise
         assert np.allclose(c.numpy(), g[key + "_cost_f64"], rtol=1e-8)
         assert np.allclose(gu.numpy(), g[key + "_gu_f64"], rtol=1e-6, atol=1e-8 * np.abs(g[key + "_gu_f64"]).max())
+
+
+# ----------------------------------------------------------------------------- training side: G14-G16
+WG_MODELS = ["phnn_cartpole", "canonical_cartpole", "phnn_pendulum", "odefunc_pendulum"]
+
+
+@pytest.fixture(scope="module")
+def wg():
+    return ol.load_wgrad_golden()
+
+
+def assert_param_grads(named, g, prefix, tag, rtol, what):
+    """every parameter of the reference's named_parameters(): |ours - ref| <= rtol * max|ref| of that tensor
+    (an all-zero reference gradient -- buffers, autograd constants, unused rows -- must be exactly zero)."""
+    keys = [k for k in g if k.startswith(prefix + "g.") and k.endswith("_" + tag)]
+    assert keys, prefix
+    for k in keys:
+        name = k[len(prefix) + 2:-len(tag) - 1]
+        ref = np.asarray(g[k], np.float64)
+        ours = np.asarray(named[name], np.float64).reshape(ref.shape)
+        mx = np.abs(ref).max()
+        if mx == 0:
+            assert np.all(ours == 0), (what, name)
+        else:
+            assert np.abs(ours - ref).max() <= rtol * mx, (what, name, np.abs(ours - ref).max() / mx)
+
+
+@pytest.mark.parametrize("name", WG_MODELS)
+def test_oracle_point_wgrad_g14(wg, name):
+    from phnn_mpc_amd import weights
+    w = ol.load_weights(name)
+    m = ol.OracleModel(w, "f64")
+    pre = f"{name}/pt_"
+    g = m.wgrad(wg[pre + "x"], wg[pre + "u"], wg[pre + "lam"], wg[pre + "Hbar"])
+    assert_param_grads(weights.unpack_grad_blob(w, g), wg, pre, "f64", 1e-10, name)
+    # buffers / autograd constants keep zero gradient in the blob
+    named = weights.unpack_grad_blob(w, g)
+    for k in ("G_fixed", "G", "M_net.log_a", "M_net.b", "M_net.log_c"):
+        if k in named:
+            assert np.all(named[k] == 0)
+
+
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+@pytest.mark.parametrize("name", WG_MODELS[:3])
+def test_oracle_rollout_wgrad_g16(wg, name, integ):
+    from phnn_mpc_amd import weights
+    w = ol.load_weights(name)
+    m = ol.OracleModel(w, "f64")
+    pre = f"{name}/rw_"
+    r = m.rollout_wgrad(wg[pre + "x0"], wg[pre + "U"], integ, float(wg[pre + "dt"]), wg[pre + "traj_bar"], wg[pre + "dx_bar"])
+    assert np.allclose(r["traj"], wg[f"{pre}{integ}_traj_f64"], rtol=1e-10, atol=1e-12)
+    assert np.allclose(r["dX"], wg[f"{pre}{integ}_dX_f64"], rtol=1e-10, atol=1e-12)
+    assert np.abs(r["grad_u"] - wg[f"{pre}{integ}_gu_f64"]).max() <= 1e-10 * np.abs(wg[f"{pre}{integ}_gu_f64"]).max()
+    assert np.abs(r["grad_x0"] - wg[f"{pre}{integ}_gx0_f64"]).max() <= 1e-10 * np.abs(wg[f"{pre}{integ}_gx0_f64"]).max()
+    assert_param_grads(weights.unpack_grad_blob(w, r["grad_theta"]), wg, f"{pre}{integ}_", "f64", 1e-9, (name, integ))
