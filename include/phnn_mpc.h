@@ -91,7 +91,10 @@ typedef struct {
   int32_t matmul_mode;  /* phnn_matmul_mode */
   int32_t force_matmul; /* 1: accept matmul_mode even where it is known to miss the stated tolerance (64-wide + f16x2) */
   int32_t max_waves;    /* waves per workgroup cap, 1..8; 0 = default (8).  4 = one wave per SIMD (diagnostics) */
-  int32_t reserved[5];  /* must be zero */
+  int32_t split_tiles;  /* small-batch kernels (four waves share one 16-rollout tile; bitwise the same results):
+                         * 0 = automatic (used while the batch has at most 2 tiles per CU), 1 = never, 2 = always
+                         * (where the variant has them: 128-wide f16x2 pHNN with fixed G, canonical pHNN) */
+  int32_t reserved[4];  /* must be zero */
 } phnn_options;
 
 /* Stage cost of both controllers:

@@ -16,6 +16,7 @@ INTEGRATORS = {"euler": INTEG_EULER, "rk4": INTEG_RK4}
 
 ACT_TANH, ACT_OTHER = 0, 1
 MATMUL_MODES = {"default": 0, "f32": 1, "bf16x3": 2, "f16x2": 3}
+SPLIT_MODES = {"auto": 0, "never": 1, "always": 2}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PHNN_LIB_PATH: load another build of the library (A/B comparisons, tools/ab_bench.sh) without touching the product file
@@ -63,7 +64,7 @@ class Plant(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("matmul_mode", C.c_int32), ("force_matmul", C.c_int32), ("max_waves", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("split_tiles", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Cost(C.Structure):

@@ -29,6 +29,8 @@ constexpr int kScrFloats = 16 * 20;  // per-wave LDS scratch: 16 rollouts x (16 
 
 struct Lane {
   int lane, i, q;
+  int w;        // split-tile kernels: which quarter of every hidden vector this wave owns (tiles 2w, 2w+1); else 0
+  float* xch;   // split-tile kernels: LDS exchange area of the workgroup; else null
 };
 
 template <int T>
@@ -486,36 +488,27 @@ DEV void sq_bwd_h(Act<T>& o, const float* Wimg, Lane ln, const Split2<T>& in) {
 // Uses the 16-block v_mfma_f32_4x4x1 (8 cycles): block b = lane>>2 = 4q + (i>>2) multiplies A_b[c][0] = Wt[c = i&3]
 // [unit 16t+4q+r] with B_b[0][j = i&3] = the accumulator value of rollout i, i.e. one k per k-slot q and a group of
 // four rollouts per block -- exactly the register contents we have.  Each lane then holds, in register c, output c of
-// its rollout summed over ITS k-slot's units; the four k-slots are added with two cross-lane steps.  32 MFMAs x 8
-// cycles + 8 shuffles instead of 32 MFMAs x 32 cycles for the replicated-row 16x16x4 form (PHNN_TO4_REP selects it).
-template <int TI>
-DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
-  constexpr int LR = 16 * TI + 8;
-  keep_lds_reads_local();
-  const float* base = Wt + (ln.i & 3) * LR + 4 * ln.q;
+// its rollout summed over ITS k-slot's units; the four k-slots are added with two cross-lane steps.
+// Association (fixed, part of the bitwise contract between the whole-tile and the split-tile kernels): the units are
+// summed in groups of two tiles (32 units: two interleaved chains o0, o1, P = o0 + o1), the group sums are added left
+// to right, then the k-slots.  A tile split over four waves (wave w = group w) reproduces exactly this.
+template <int TG>
+DEV f32x4 to4_group(const float* Wt_group, Lane ln, const f32x4* in_tiles) {  // partial sum of TG tiles, before the k-slot sum
+  const float* base = Wt_group + 4 * ln.q;
   f32x4 o0 = splat4(0.f), o1 = splat4(0.f);
-#ifdef PHNN_TO4_REP
 #pragma unroll
-  for (int t = 0; t < TI; ++t) {
+  for (int t = 0; t < TG; ++t) {
     f32x4 a = *reinterpret_cast<const f32x4*>(base + 16 * t);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if ((t & 1) == 0) o0 = mfma(a[r], in.v[t][r], o0);
-      else o1 = mfma(a[r], in.v[t][r], o1);
+      if ((r & 1) == 0) o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], in_tiles[t][r], o0, 0, 0, 0);
+      else o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], in_tiles[t][r], o1, 0, 0, 0);
     }
   }
   return o0 + o1;
-#else
-#pragma unroll
-  for (int t = 0; t < TI; ++t) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(base + 16 * t);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if ((r & 1) == 0) o0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], in.v[t][r], o0, 0, 0, 0);
-      else o1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[r], in.v[t][r], o1, 0, 0, 0);
-    }
-  }
-  f32x4 o = o0 + o1;
+}
+
+DEV f32x4 to4_kslots(f32x4 o) {  // sum over the four k-slots (lanes q = 0..3 of a rollout)
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     float v = o[c];
@@ -524,7 +517,18 @@ DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
     o[c] = v;
   }
   return o;
-#endif
+}
+
+template <int TI>
+DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
+  constexpr int LR = 16 * TI + 8;
+  keep_lds_reads_local();
+  const float* row = Wt + (ln.i & 3) * LR;
+  constexpr int TG = TI >= 2 ? 2 : 1, NG = TI / TG;
+  f32x4 tot = to4_group<TG>(row, ln, &in.v[0]);
+#pragma unroll
+  for (int g = 1; g < NG; ++g) tot = tot + to4_group<TG>(row + 16 * TG * g, ln, &in.v[TG * g]);
+  return to4_kslots(tot);
 }
 
 // Per-wave stash in HBM (K1 -> K2): one activation vector = T x 64 lanes x float4, i.e. one fully coalesced
@@ -795,6 +799,55 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v, float* rec 
   return Hv * (-2.0f * unscale * L[Y::oB3 + 2]);  // oB3[2]: 1 / (scale folded into W1)
 }
 
+// HID -> 16 output layer of R_net / G_net on the hi/lo fragments of the hidden activations (f16x2): lane (i,q) gets outputs 4q..4q+3
+template <int HID, int MM>
+DEV f32x4 h1_out_hf(const float* L, Lane ln, const Split2<HID / 16>& sp) {
+  using Y = LayH1<HID, MM>;
+  constexpr int T = Y::T;
+  keep_lds_reads_local();
+  const char* base = reinterpret_cast<const char*>(L + Y::oV2) + ln.i * (Y::RS * 2) + ln.q * 16;
+  f32x4 o0 = splat4(0.f), o1 = splat4(0.f), o2 = splat4(0.f);
+#pragma unroll
+  for (int s = 0; s < T / 2; ++s) {
+    f16x8 ah = *reinterpret_cast<const f16x8*>(base + s * 64);
+    f16x8 al = *reinterpret_cast<const f16x8*>(base + Y::FPART + s * 64);
+    o0 = mfma_h(al, sp.h[s], o0);
+    o1 = mfma_h(ah, sp.l[s], o1);
+    o2 = mfma_h(ah, sp.h[s], o2);
+  }
+  const float inv = L[Y::oSc];
+  f32x4 c2 = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
+  return ((o0 + o1) + o2) * inv + c2;
+}
+
+// B operands of the transposed output layer (f16x2): obar normalised per rollout by a power of two, split hi/lo and
+// stacked along K (see h1_bwd).  unscale = 2^e / Sr.
+template <int HID, int MM>
+DEV void h1_bwd_operands(const float* L, Lane ln, const float (&obar)[16], f16x8& b1, f16x8& b2, float& unscale) {
+  using Y = LayH1<HID, MM>;
+  float mx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) mx = fmaxf(mx, __builtin_fabsf(obar[k]));
+  int e = 0;
+  (void)__builtin_frexpf(mx, &e);
+  e = (mx > 0.f && mx < 3.0e38f) ? e : 0;
+  const float sc = __builtin_ldexpf(1.0f, -e);
+  unscale = __builtin_ldexpf(1.0f, e) * L[Y::oSc];
+  const bool second = (ln.q & 1) != 0, lo_half = ln.q >= 2;
+  u32x4 B1, B2;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 v = {(second ? obar[8 + 2 * p] : obar[2 * p]) * sc, (second ? obar[9 + 2 * p] : obar[2 * p + 1]) * sc};
+    f16x2 hb2 = __builtin_convertvector(v, f16x2);
+    f32x2 r = residual_h(hb2, v);
+    unsigned hbits = __builtin_bit_cast(unsigned, hb2), lbits = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    B1[p] = lo_half ? lbits : hbits;
+    B2[p] = lo_half ? 0u : hbits;
+  }
+  b1 = __builtin_bit_cast(f16x8, B1);
+  b2 = __builtin_bit_cast(f16x8, B2);
+}
+
 // one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations.
 // MM_F16X2: the HID -> 16 output layer runs as 3 x T/2 v_mfma_f32_16x16x32_f16 (three independent chains) on the
 // hi/lo split of the hidden activations instead of 2T dependent-pair f32 MFMAs of 32 cycles each.
@@ -809,20 +862,7 @@ DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, 
   if (Y::HF) {
     Split2<T> sp;
     split_act_h<T>(h, sp);
-    keep_lds_reads_local();
-    const char* base = reinterpret_cast<const char*>(L + Y::oV2) + ln.i * (Y::RS * 2) + ln.q * 16;
-    f32x4 o0 = splat4(0.f), o1 = splat4(0.f), o2 = splat4(0.f);
-#pragma unroll
-    for (int s = 0; s < T / 2; ++s) {
-      f16x8 ah = *reinterpret_cast<const f16x8*>(base + s * 64);
-      f16x8 al = *reinterpret_cast<const f16x8*>(base + Y::FPART + s * 64);
-      o0 = mfma_h(al, sp.h[s], o0);
-      o1 = mfma_h(ah, sp.l[s], o1);
-      o2 = mfma_h(ah, sp.h[s], o2);
-    }
-    const float inv = L[Y::oSc];
-    f32x4 c2 = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
-    o.v[0] = ((o0 + o1) + o2) * inv + c2;
+    o.v[0] = h1_out_hf<HID, MM>(L, ln, sp);
   } else {
     o.v[0] = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
     sq_fwd<1, T>(o, L + Y::oV2, ln, h);
@@ -841,26 +881,8 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
   Act<T> hb;
   float unscale = 1.0f;
   if (Y::HF) {
-    float mx = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) mx = fmaxf(mx, __builtin_fabsf(obar[k]));
-    int e = 0;
-    (void)__builtin_frexpf(mx, &e);
-    e = (mx > 0.f && mx < 3.0e38f) ? e : 0;
-    const float sc = __builtin_ldexpf(1.0f, -e);
-    unscale = __builtin_ldexpf(1.0f, e) * L[Y::oSc];
-    const bool second = (ln.q & 1) != 0, lo_half = ln.q >= 2;
-    u32x4 B1, B2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      f32x2 v = {(second ? obar[8 + 2 * p] : obar[2 * p]) * sc, (second ? obar[9 + 2 * p] : obar[2 * p + 1]) * sc};
-      f16x2 hb2 = __builtin_convertvector(v, f16x2);
-      f32x2 r = residual_h(hb2, v);
-      unsigned hbits = __builtin_bit_cast(unsigned, hb2), lbits = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-      B1[p] = lo_half ? lbits : hbits;
-      B2[p] = lo_half ? 0u : hbits;
-    }
-    const f16x8 b1 = __builtin_bit_cast(f16x8, B1), b2 = __builtin_bit_cast(f16x8, B2);
+    f16x8 b1, b2;
+    h1_bwd_operands<HID, MM>(L, ln, obar, b1, b2, unscale);
     keep_lds_reads_local();
     const char* base = reinterpret_cast<const char*>(L + Y::oV2T) + ln.i * 32 + (ln.q & 1) * 16;
 #pragma unroll
@@ -890,7 +912,7 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
 template <int N_, int HID_, bool FIXG_, int MM_ = MM_F32>
 struct PhnnModel {
   static constexpr int N = N_, HID = HID_, T = HID / 16, MM = MM_;
-  static constexpr bool FIXG = FIXG_;
+  static constexpr bool FIXG = FIXG_, SPLIT = false;
   static constexpr int SCR = kScrFloats;  // per-wave LDS scratch (exchange of the 16 R_net / G_net outputs)
   static constexpr int oH = 0;
   static constexpr int oR = oH + LayH2<HID, MM>::SIZE;
@@ -1069,6 +1091,7 @@ struct PhnnModel {
 template <int HID_, int MM_ = MM_F32>
 struct CanonModel {
   static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_;
+  static constexpr bool SPLIT = false;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int oH = 0;
   static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // [16]: a, b, c, 0, Rd[4], G[4], sigmoid(R_diag_raw)[4]
@@ -1163,11 +1186,459 @@ struct CanonModel {
 };
 
 // ------------------------------------------------------------------------------------------------
+// Split-tile models: FOUR waves share one 16-rollout tile (small batches, single plants).
+//
+// With fewer than ~2 tiles per CU the whole-tile kernels leave one wave per CU marching alone (every vector
+// instruction issued by a single wave, three SIMDs idle).  Here the hidden units are split instead: wave w of a
+// 4-wave workgroup owns accumulator tiles 2w, 2w+1 of every 128-wide vector -- exactly k-step s = w of the next
+// hidden x hidden product, whose B fragment lane (i,q) builds from tiles 2s, 2s+1 of the SAME lane.  Exchange between
+// layers: each wave writes the hi/lo fragments of its own k-step (2 x 16 B per lane) to LDS, one barrier, every wave
+// reads the four k-steps (8 x 16 B per lane, conflict-free) and runs its 2 output tiles x 4 k-steps x 3 products =
+// 24 MFMAs instead of 96; tanh, splits and the element-wise adjoint work shrink by four as well.  The 128 -> 4
+// reductions leave one partial per wave (to4_group), summed in the fixed order of to4_rep; the small 128 -> 16 output
+// layer of R_net runs redundantly on all four waves from the exchanged fragments.  Every sum keeps the association of
+// the whole-tile kernels, so results are BITWISE identical to them (tests compare slices of a large batch, run by the
+// whole-tile kernels, with the same rollouts run alone by these).  The stash format is the same too.
+// Exchange area (floats): three fragment regions [part 2][k-step 4][lane 64] x 16 B, two partial-sum sets
+// [wave 4][lane 64] x 16 B.  HID = 128, f16x2 products only.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXR0 = 0, kXR1 = 2048, kXR2 = 4096, kXP0 = 6144, kXP1 = 7168, kXchFloats = 8192;
+using ActW = Act<2>;
+
+DEV void xch_put(float* region, Lane ln, const Split2<2>& sp) {  // this wave's k-step (= ln.w)
+  f16x8* p = reinterpret_cast<f16x8*>(region);
+  p[ln.w * 64 + ln.lane] = sp.h[0];
+  p[(4 + ln.w) * 64 + ln.lane] = sp.l[0];
+}
+DEV void xch_get(const float* region, Lane ln, Split2<8>& o) {
+  const f16x8* p = reinterpret_cast<const f16x8*>(region);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    o.h[s] = p[s * 64 + ln.lane];
+    o.l[s] = p[(4 + s) * 64 + ln.lane];
+  }
+}
+DEV void xch_put_partial(float* set, Lane ln, f32x4 v) { reinterpret_cast<f32x4*>(set)[ln.w * 64 + ln.lane] = v; }
+DEV f32x4 xch_sum_partials(const float* set, Lane ln) {  // ((P0 + P1) + P2) + P3, then the k-slots: to4_rep's order
+  const f32x4* p = reinterpret_cast<const f32x4*>(set) + ln.lane;
+  return to4_kslots(((p[0] + p[64]) + p[128]) + p[192]);
+}
+
+DEV void tanh_pre_w(ActW& a) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.v[t][r] = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a.v[t][r]) + 1.0f), 1.0f);
+}
+
+// o (tiles 2w, 2w+1) += rows of W times the full vector given as four k-step fragments; same chain per tile as sq_fwd_h
+DEV void sq_fwd_h_w(ActW& o, const float* Wimg, Lane ln, const Split2<8>& in) {
+  using I = HfImg<128>;
+  keep_lds_reads_local();
+  matrix_phase_begin();
+  const char* base = reinterpret_cast<const char*>(Wimg) + ln.i * (I::RS * 2) + ln.q * 16 + (2 * ln.w) * 16 * (I::RS * 2);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f16x8 a[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) a[g][p] = *reinterpret_cast<const f16x8*>(base + p * I::PART + g * 16 * (I::RS * 2) + s * 64);
+    mfma3x2(o.v[0], o.v[1], a, in.h[s], in.l[s]);
+  }
+  matrix_phase_end();
+}
+
+// o (tiles 2w, 2w+1) += columns of W (W^T product) times the full vector; same chain per tile as sq_bwd_h
+DEV void sq_bwd_h_w(ActW& o, const float* Wimg, Lane ln, const Split2<8>& in) {
+  using I = HfImg<128>;
+  keep_lds_reads_local();
+  matrix_phase_begin();
+  typedef fp16x4_t __attribute__((address_space(3))) * lds_h4;
+  typedef char __attribute__((address_space(3))) * lds_cp;
+  const int a4 = (ln.lane & 15) >> 2, pp = ln.lane & 3;
+  lds_cp base = (lds_cp) const_cast<char*>(reinterpret_cast<const char*>(Wimg)) + (4 * ln.q + a4) * (I::RS * 2) + 16 * pp + 64 * ln.w;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f16x8 a[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        lds_cp off = base + p * I::PART + 32 * s * (I::RS * 2) + 8 * g;
+        f16x4 lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)off));
+        f16x4 hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(off + 16 * (I::RS * 2))));
+        a[g][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    mfma3x2(o.v[0], o.v[1], a, in.h[s], in.l[s]);
+  }
+  matrix_phase_end();
+}
+
+// H_net of a split tile: forward to (a1, a2, q1) on the own tiles and the wave's partial of dH (to4_group).
+// Barriers: two inside (after the a1 and after the g2 fragments).  `pre_barrier` runs between the first fragment write
+// and the first barrier (R_net's first layer shares that barrier).
+struct HTapeW {
+  ActW a1, a2, q1;
+};
+
+template <class PreBarrier>
+DEV f32x4 hnet_grad_w(const float* L, Lane ln, f32x4 z, HTapeW& tp, PreBarrier pre_barrier) {
+  using Y = LayH2<128, MM_F16X2>;
+  const int t0 = 2 * ln.w;
+  load_vec<2>(tp.a1, L + Y::oB1 + 16 * t0, ln);
+  in_layer<2>(tp.a1, L + Y::oW1f + 64 * t0, ln, sel4(z, ln.q));
+  tanh_pre_w(tp.a1);
+  {
+    Split2<2> sp;
+    split_act_h<2>(tp.a1, sp);
+    xch_put(ln.xch + kXR0, ln, sp);
+  }
+  pre_barrier();
+  __syncthreads();
+  {
+    Split2<8> all;
+    xch_get(ln.xch + kXR0, ln, all);
+    load_vec<2>(tp.a2, L + Y::oB2 + 16 * t0, ln);
+    sq_fwd_h_w(tp.a2, L + Y::oW2, ln, all);
+  }
+  const float c = L[Y::oB3 + 1];
+  if (c == 1.0f) {
+    tanh_pre_w(tp.a2);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tp.a2.v[t][r] = tanh_scaled(tp.a2.v[t][r], c);
+  }
+  ActW g;
+  keep_lds_reads_local();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x4 w3b = *reinterpret_cast<const f32x4*>(L + Y::oW3B + 16 * (t0 + t) + 4 * ln.q);
+    g.v[t] = w3b * dtanh(tp.a2.v[t]);
+  }
+  {
+    Split2<2> sp;
+    split_act_h<2>(g, sp);
+    xch_put(ln.xch + kXR1, ln, sp);
+  }
+  __syncthreads();
+  {
+    Split2<8> all;
+    xch_get(ln.xch + kXR1, ln, all);
+    zero_act<2>(tp.q1);
+    sq_bwd_h_w(tp.q1, L + Y::oW2, ln, all);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) g.v[t] = tp.q1.v[t] * dtanh(tp.a1.v[t]);
+  keep_lds_reads_local();
+  return to4_group<2>(L + Y::oW1T + (ln.i & 3) * Y::LR + 16 * t0, ln, g.v);
+}
+
+// Hessian-vector product of a split tile: the wave's partial (before the partial sum, the k-slot sum and the final
+// scale); `scale` receives that final factor.  Two barriers inside.  Consumes tp.q1 like hnet_hvp.
+DEV f32x4 hnet_hvp_w(const float* L, Lane ln, HTapeW& tp, f32x4 v, float& scale) {
+  using Y = LayH2<128, MM_F16X2>;
+  const int t0 = 2 * ln.w;
+  float mx = fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+  int e = 0;
+  (void)__builtin_frexpf(mx, &e);
+  e = (mx > 0.f && mx < 3.0e38f) ? e : 0;
+  v = v * __builtin_ldexpf(1.0f, -e);
+  const float unscale = __builtin_ldexpf(1.0f, e);
+  ActW ad1, w;
+  zero_act<2>(ad1);
+  in_layer<2>(ad1, L + Y::oW1f + 64 * t0, ln, sel4(v, ln.q));
+#pragma unroll
+  for (int t = 0; t < 2; ++t) ad1.v[t] = dtanh(tp.a1.v[t]) * ad1.v[t];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) tp.q1.v[t] = tp.q1.v[t] * (tp.a1.v[t] * ad1.v[t]);
+  {
+    Split2<2> sp;
+    split_act_h<2>(ad1, sp);
+    xch_put(ln.xch + kXR0, ln, sp);
+  }
+  __syncthreads();
+  {
+    Split2<8> all;
+    xch_get(ln.xch + kXR0, ln, all);
+    zero_act<2>(w);
+    sq_fwd_h_w(w, L + Y::oW2, ln, all);
+  }
+  keep_lds_reads_local();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3S + 16 * (t0 + t) + 4 * ln.q);
+    f32x4 a2 = tp.a2.v[t];
+    f32x4 ad2 = dtanh(a2) * w.v[t];
+    w.v[t] = w3 * (a2 * ad2);
+  }
+  {
+    Split2<2> sp;
+    split_act_h<2>(w, sp);
+    xch_put(ln.xch + kXR1, ln, sp);
+  }
+  __syncthreads();
+  ActW qd;
+  {
+    Split2<8> all;
+    xch_get(ln.xch + kXR1, ln, all);
+    zero_act<2>(qd);
+    sq_bwd_h_w(qd, L + Y::oW2, ln, all);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) qd.v[t] = __builtin_elementwise_fma(qd.v[t], dtanh(tp.a1.v[t]), tp.q1.v[t]);
+  scale = -2.0f * unscale * L[Y::oB3 + 2];
+  keep_lds_reads_local();
+  return to4_group<2>(L + Y::oW1T + (ln.i & 3) * Y::LR + 16 * t0, ln, qd.v);
+}
+
+template <int N_>
+struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split over four waves
+  using Base = PhnnModel<N_, 128, true, MM_F16X2>;
+  static constexpr int N = N_, HID = 128, T = 8, MM = MM_F16X2;
+  static constexpr bool FIXG = true, SPLIT = true;
+  static constexpr int SCR = Base::SCR, IMG = Base::IMG, STASH = Base::STASH;
+  static constexpr int oH = Base::oH, oR = Base::oR, oJ = Base::oJ, oG = Base::oG;
+  using YR = LayH1<128, MM_F16X2>;
+
+  // R_net hidden layer on the own tiles; fragments to region 2
+  DEV static void rnet_layer1(const float* L, Lane ln, f32x4 x, ActW& hR) {
+    const int t0 = 2 * ln.w;
+    load_vec<2>(hR, L + oR + YR::oC1 + 16 * t0, ln);
+    in_layer<2>(hR, L + oR + YR::oV1f + 64 * t0, ln, sel4(x, ln.q));
+    tanh_pre_w(hR);
+    Split2<2> sp;
+    split_act_h<2>(hR, sp);
+    xch_put(ln.xch + kXR2, ln, sp);
+  }
+  // R_net outputs from the exchanged fragments (after a barrier): all 16 in every lane
+  DEV static void rnet_out(const float* L, float* scr, Lane ln, float (&rf)[16]) {
+    Split2<8> all;
+    xch_get(ln.xch + kXR2, ln, all);
+    f32x4 o = h1_out_hf<128, MM_F16X2>(L + oR, ln, all);
+    gather16(scr, ln, o, rf);
+  }
+
+  template <bool WANT_H, bool ST = false>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
+    static_assert(!WANT_H, "the split-tile kernels are rollout kernels");
+    keep_lds_reads_local();
+    HTapeW tp;
+    ActW hR;
+    f32x4 P = hnet_grad_w(L + oH, ln, x, tp, [&]() { rnet_layer1(L, ln, x, hR); });
+    xch_put_partial(ln.xch + kXP0, ln, P);
+    float rf[16];
+    rnet_out(L, scr, ln, rf);
+    if (ST) {
+      store_act<2>(stash + 2 * ln.w * 256, ln, tp.a2);
+      store_act<2>(stash + T * 256 + 2 * ln.w * 256, ln, tp.q1);
+    }
+    __syncthreads();
+    f32x4 dH = xch_sum_partials(ln.xch + kXP0, ln);
+    if (ST && ln.q == 0 && ln.w == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+    float G[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) G[i] = L[oG + i];
+    return Base::combine(L, rf, dH, G, u);
+  }
+
+  template <bool ST = false, bool WG = false>
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar,
+                      const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
+    static_assert(!WG, "weight-gradient records come from the whole-tile kernels");
+    keep_lds_reads_local();
+    const int t0 = 2 * ln.w;
+    HTapeW tp;
+    ActW hR;
+    f32x4 dH;
+    float rf[16];
+    if (ST) {
+      load_act<2>(stash + t0 * 256, ln, tp.a2);
+      load_act<2>(stash + T * 256 + t0 * 256, ln, tp.q1);
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      using Y = LayH2<128, MM_F16X2>;
+      load_vec<2>(tp.a1, L + oH + Y::oB1 + 16 * t0, ln);
+      in_layer<2>(tp.a1, L + oH + Y::oW1f + 64 * t0, ln, sel4(x, ln.q));
+      tanh_pre_w(tp.a1);
+      rnet_layer1(L, ln, x, hR);
+      __syncthreads();
+      rnet_out(L, scr, ln, rf);
+    } else {
+      f32x4 P = hnet_grad_w(L + oH, ln, x, tp, [&]() { rnet_layer1(L, ln, x, hR); });
+      xch_put_partial(ln.xch + kXP0, ln, P);
+      rnet_out(L, scr, ln, rf);
+      __syncthreads();
+      dH = xch_sum_partials(ln.xch + kXP0, ln);
+    }
+    float S[N][N], Stl[N], StdH[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) S[i][j] = (rf[i * N + j] + rf[j * N + i]) * 0.5f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float a = 0.f, c = 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        a = __builtin_fmaf(S[i][k], lam[i], a);
+        c = __builtin_fmaf(S[i][k], dH[i], c);
+      }
+      Stl[k] = a;
+      StdH[k] = c;
+    }
+    float rbar[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rbar[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        float sij = -(lam[i] * StdH[j] + dH[i] * Stl[j]);
+        float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
+        rbar[i * N + j] = (sij + sji) * 0.5f;
+      }
+    // transposed output layer of R_net on the own tiles, then the wave's partial of V1^T (.)
+    float unscaleR;
+    f32x4 PR;
+    {
+      f16x8 b1, b2;
+      h1_bwd_operands<128, MM_F16X2>(L + oR, ln, rbar, b1, b2, unscaleR);
+      keep_lds_reads_local();
+      const char* base = reinterpret_cast<const char*>(L + oR + YR::oV2T) + ln.i * 32 + (ln.q & 1) * 16;
+      ActW hb;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f16x8 ah = *reinterpret_cast<const f16x8*>(base + (t0 + t) * 512);
+        f16x8 al = *reinterpret_cast<const f16x8*>(base + YR::BPART + (t0 + t) * 512);
+        hb.v[t] = mfma_h(ah, b1, mfma_h(al, b2, splat4(0.f)));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) hb.v[t] = hb.v[t] * dtanh(hR.v[t]);
+      keep_lds_reads_local();
+      PR = to4_group<2>(L + oR + YR::oV1T + (ln.i & 3) * YR::LR + 16 * t0, ln, hb.v);
+    }
+    ubar = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ubar = __builtin_fmaf(L[oG + i], lam[i], ubar);
+    f32x4 v = splat4(0.f);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc = __builtin_fmaf(L[oJ + i * N + j], lam[i], acc);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[j][k], Stl[k], acc);
+      v[j] = acc;
+    }
+    float scaleH;
+    f32x4 PH = hnet_hvp_w(L + oH, ln, tp, v, scaleH);
+    xch_put_partial(ln.xch + kXP0, ln, PR);
+    xch_put_partial(ln.xch + kXP1, ln, PH);
+    __syncthreads();
+    f32x4 xb = splat4(0.f);
+    xb += xch_sum_partials(ln.xch + kXP0, ln) * unscaleR;
+    xbar = xb + xch_sum_partials(ln.xch + kXP1, ln) * scaleH;
+  }
+};
+
+template <int DUMMY = 0>
+struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four waves
+  using Base = CanonModel<128, MM_F16X2>;
+  static constexpr int N = 4, HID = 128, T = 8, MM = MM_F16X2;
+  static constexpr bool SPLIT = true;
+  static constexpr int SCR = 0, IMG = Base::IMG, STASH = Base::STASH, oH = Base::oH, oC = Base::oC;
+
+  template <bool WANT_H, bool ST = false>
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, float u, float& Hval, float* stash = nullptr) {
+    static_assert(!WANT_H, "the split-tile kernels are rollout kernels");
+    keep_lds_reads_local();
+    float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
+    float sn, cs;
+    sincos_dev(y[1], sn, cs);
+    float bc = b * cs;
+    f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
+    HTapeW tp;
+    f32x4 P = hnet_grad_w(L + oH, ln, z, tp, []() {});
+    xch_put_partial(ln.xch + kXP0, ln, P);
+    if (ST) {
+      store_act<2>(stash + 2 * ln.w * 256, ln, tp.a2);
+      store_act<2>(stash + T * 256 + 2 * ln.w * 256, ln, tp.q1);
+    }
+    __syncthreads();
+    f32x4 dH = xch_sum_partials(ln.xch + kXP0, ln);
+    if (ST && ln.q == 0 && ln.w == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+    float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + L[oC + 10] * u;
+    float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + L[oC + 11] * u;
+    float det = (a * c - bc * bc) + 1e-6f;
+    float mi00 = c / det, mi01 = -bc / det, mi11 = a / det;
+    return f32x4{mi00 * z[2] + mi01 * z[3], mi01 * z[2] + mi11 * z[3], mi00 * dp0 + mi01 * dp1,
+                 mi01 * dp0 + mi11 * dp1};
+  }
+
+  template <bool ST = false, bool WG = false>
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, float u, f32x4 lam, f32x4& ybar, float& ubar,
+                      const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
+    static_assert(!WG, "weight-gradient records come from the whole-tile kernels");
+    keep_lds_reads_local();
+    const int t0 = 2 * ln.w;
+    float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
+    float sn, cs;
+    sincos_dev(y[1], sn, cs);
+    float bc = b * cs;
+    f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
+    HTapeW tp;
+    f32x4 dH;
+    if (ST) {
+      load_act<2>(stash + t0 * 256, ln, tp.a2);
+      load_act<2>(stash + T * 256 + t0 * 256, ln, tp.q1);
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      using Y = LayH2<128, MM_F16X2>;
+      load_vec<2>(tp.a1, L + oH + Y::oB1 + 16 * t0, ln);
+      in_layer<2>(tp.a1, L + oH + Y::oW1f + 64 * t0, ln, sel4(z, ln.q));
+      tanh_pre_w(tp.a1);
+    } else {
+      f32x4 P = hnet_grad_w(L + oH, ln, z, tp, []() {});
+      xch_put_partial(ln.xch + kXP0, ln, P);
+      __syncthreads();
+      dH = xch_sum_partials(ln.xch + kXP0, ln);
+    }
+    float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
+    float dp0 = (-dH[0] - Rd2 * dH[2]) + L[oC + 10] * u;
+    float dp1 = (-dH[1] - Rd3 * dH[3]) + L[oC + 11] * u;
+    float det = (a * c - bc * bc) + 1e-6f;
+    float rdet = 1.0f / det;
+    float mi00 = c * rdet, mi01 = -bc * rdet, mi11 = a * rdet;
+    float pb0 = lam[0] * mi00 + lam[1] * mi01, pb1 = lam[0] * mi01 + lam[1] * mi11;
+    float dpb0 = lam[2] * mi00 + lam[3] * mi01, dpb1 = lam[2] * mi01 + lam[3] * mi11;
+    float mb00 = lam[0] * z[2] + lam[2] * dp0;
+    float mb01 = lam[0] * z[3] + lam[1] * z[2] + lam[2] * dp1 + lam[3] * dp0;
+    float mb11 = lam[1] * z[3] + lam[3] * dp1;
+    f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
+    ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
+    float scaleH;
+    f32x4 PH = hnet_hvp_w(L + oH, ln, tp, v, scaleH);
+    xch_put_partial(ln.xch + kXP1, ln, PH);
+    __syncthreads();
+    f32x4 zb = xch_sum_partials(ln.xch + kXP1, ln) * scaleH;
+    zb[2] += pb0;
+    zb[3] += pb1;
+    float bcb = zb[2] * y[3] + zb[3] * y[2];
+    float detb = (-(mb00 * c + mb11 * a) + mb01 * bc) * (rdet * rdet);
+    bcb += -mb01 * rdet;
+    bcb += -2.0f * bc * detb;
+    ybar = f32x4{zb[0], zb[1] + bcb * (-b * sn), zb[2] * a + zb[3] * bc, zb[2] * bc + zb[3] * c};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // Model: ODEFunc MLP [x,u] -> HID -> HID -> HID -> n  (src/baseline_node.py:60-116), n + m <= 4
 // ------------------------------------------------------------------------------------------------
 template <int N_, int HID_, int MM_ = MM_F32>
 struct OdeModel {
   static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8, MM = MM_;
+  static constexpr bool SPLIT = false;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int WF = MM == MM_F16X2 ? HfImg<HID>::FLOATS : HID * LD;  // one hidden x hidden image
   static constexpr int oW1f = 0;                   // [T][64]   W1 (HID x (n+m))
@@ -1430,15 +1901,18 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
+  ln.w = M::SPLIT ? wave : 0;
+  ln.xch = M::SPLIT ? lds + M::IMG + nwaves * M::SCR : nullptr;
   float* scr = lds + M::IMG + wave * M::SCR;
-  const long long tile = (long long)blockIdx.x * nwaves + wave;
+  // split-tile models: the workgroup's four waves share tile blockIdx.x (all four reach every barrier together)
+  const long long tile = M::SPLIT ? (long long)blockIdx.x : (long long)blockIdx.x * nwaves + wave;
   if (tile * kTileB >= p.B) return;
   long long b = tile * kTileB + ln.i;
   const bool valid = b < p.B;
   if (!valid) b = p.B - 1;
   const float* L = lds;
   f32x4 x = load_state<N>(p.x0 + b * N);
-  const bool writer = valid && ln.q == 0;
+  const bool writer = valid && ln.q == 0 && (!M::SPLIT || wave == 0);
   if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1)) * N, x);
   float cost = state_cost<N>(p.c, x);
   const float* up = p.u + b * p.H;
@@ -1475,14 +1949,16 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
+  ln.w = M::SPLIT ? wave : 0;
+  ln.xch = M::SPLIT ? lds + M::IMG + nwaves * M::SCR : nullptr;
   float* scr = lds + M::IMG + wave * M::SCR;
-  const long long tile = (long long)blockIdx.x * nwaves + wave;
+  const long long tile = M::SPLIT ? (long long)blockIdx.x : (long long)blockIdx.x * nwaves + wave;
   if (tile * kTileB >= p.B) return;
   long long b = tile * kTileB + ln.i;
   const bool valid = b < p.B;
   if (!valid) b = p.B - 1;
   const float* L = lds;
-  const bool writer = valid && ln.q == 0;
+  const bool writer = valid && ln.q == 0 && (!M::SPLIT || wave == 0);
   const float* tr = p.traj_in + (b * (p.H + 1)) * N;
   const float* up = p.u + b * p.H;
   const float cb = p.no_cost ? 0.0f : (p.cost_bar ? p.cost_bar[b] : 1.0f);
@@ -1566,6 +2042,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_forward(PointParams p)
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
+  ln.w = 0;
+  ln.xch = nullptr;
   float* scr = lds + M::IMG + wave * M::SCR;
   const long long ntiles = (p.B + kTileB - 1) / kTileB;
   for (long long tile = (long long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long long)gridDim.x * nwaves) {
@@ -1592,6 +2070,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_vjp(PointParams p) {
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
+  ln.w = 0;
+  ln.xch = nullptr;
   float* scr = lds + M::IMG + wave * M::SCR;
   const long long ntiles = (p.B + kTileB - 1) / kTileB;
   for (long long tile = (long long)blockIdx.x * nwaves + wave; tile < ntiles; tile += (long long)gridDim.x * nwaves) {
@@ -1768,6 +2248,8 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
   ln.q = ln.lane >> 4;
+  ln.w = 0;
+  ln.xch = nullptr;
   // exchange buffers: two arrays (A side: gdot2* | g2, B side: a1 | adot1) of [HID units][32 k] f32, k stored at
   // position (k & 3) * 8 + (k >> 2) so that lane (i,q) finds the operands of its 8 k-steps contiguously; x2 (ping-pong)
   constexpr int XLD = 36;  // floats per unit row (32 + pad)

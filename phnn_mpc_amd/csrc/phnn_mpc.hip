@@ -617,6 +617,8 @@ struct phnn_handle {
   KernelSet ks;
   WgradSet wg;       // weight-gradient kernels (has_wgrad)
   bool has_wgrad;
+  SplitSet sp;       // split-tile kernels for small batches (has_split)
+  bool has_split;
   int* d_unpad;      // index map original blob -> padded blob (k_wgrad_finish)
   int n_params;      // floats of the original blob
   float* d_img;
@@ -659,6 +661,20 @@ int launch(phnn_handle* h, void (*kern)(P), const P& p, long long tiles, bool gr
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * waves), shmem, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, e, "kernel launch");
+  return PHNN_OK;
+}
+
+// Small batches: with at most two 16-rollout tiles per CU the whole-tile kernels run one wave per SIMD at best (one
+// wave per CU below n_cu tiles); the split-tile kernels put four waves on every tile instead (same results, bit for bit).
+bool use_split(const phnn_handle* h, long long tiles) {
+  if (!h->has_split || h->opt.split_tiles == 1) return false;
+  return h->opt.split_tiles == 2 || tiles <= 2LL * h->n_cu;
+}
+
+int launch_split(phnn_handle* h, void (*kern)(RollParams), const RollParams& p, long long tiles, hipStream_t st) {
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), sizeof(float) * (size_t)h->sp.lds_floats, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(h, e, "kernel launch (split-tile)");
   return PHNN_OK;
 }
 
@@ -742,8 +758,8 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   memset(&opt, 0, sizeof opt);
   if (opt_in) opt = *opt_in;
   if (opt.matmul_mode < PHNN_MATMUL_DEFAULT || opt.matmul_mode > PHNN_MATMUL_F16X2 || opt.max_waves < 0 ||
-      opt.max_waves > kMaxWaves)
-    return fail(nullptr, PHNN_ERR_INVALID_ARG, "phnn_options: matmul_mode or max_waves out of range");
+      opt.max_waves > kMaxWaves || opt.split_tiles < 0 || opt.split_tiles > 2)
+    return fail(nullptr, PHNN_ERR_INVALID_ARG, "phnn_options: matmul_mode, max_waves or split_tiles out of range");
   std::string why;
   phnn_desc pdesc;
   std::vector<float> img;
@@ -769,6 +785,7 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   h->n_params = (int)n_floats;
   kernel_set(v, &h->ks);
   h->has_wgrad = phnn_wgrad_kernels(v, &h->wg);
+  h->has_split = phnn_split_kernels(v, &h->sp);
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, device);
   h->n_cu = (e == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -790,6 +807,15 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
     if (e == hipSuccess) e = allow_big_lds(h->wg.grad[1]);
     if (e == hipSuccess) e = allow_big_lds(h->wg.mvjp);
     if (e == hipSuccess) e = allow_big_lds(h->wg.reduce);
+  }
+  if (h->has_split) {
+    if (e == hipSuccess) e = allow_big_lds(h->sp.fwd[0]);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.fwd[1]);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.fwd_stash);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.grad[0]);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.grad[1]);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.grad_stash);
+    if ((size_t)h->sp.lds_floats * sizeof(float) > 160 * 1024) h->has_split = false;
   }
   if (e != hipSuccess) {
     delete h;
@@ -912,8 +938,10 @@ int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   p.traj = traj_dev;
   const bool stash = workspace_dev && integrator == PHNN_INTEG_EULER;
   p.stash = stash ? (float*)workspace_dev : nullptr;
-  return launch(h, stash ? h->ks.fwd_stash : h->ks.fwd[integrator], p, (B + kTileB - 1) / kTileB, false,
-                (hipStream_t)stream);
+  const long long tiles = (B + kTileB - 1) / kTileB;
+  if (use_split(h, tiles))
+    return launch_split(h, stash ? h->sp.fwd_stash : h->sp.fwd[integrator], p, tiles, (hipStream_t)stream);
+  return launch(h, stash ? h->ks.fwd_stash : h->ks.fwd[integrator], p, tiles, false, (hipStream_t)stream);
 }
 
 int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
@@ -940,8 +968,10 @@ int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   p.grad_x0 = grad_x0_dev;
   const bool stash = workspace_dev && integrator == PHNN_INTEG_EULER;
   p.stash = stash ? (float*)workspace_dev : nullptr;
-  return launch(h, stash ? h->ks.grad_stash : h->ks.grad[integrator], p, (B + kTileB - 1) / kTileB, false,
-                (hipStream_t)stream);
+  const long long tiles = (B + kTileB - 1) / kTileB;
+  if (use_split(h, tiles))
+    return launch_split(h, stash ? h->sp.grad_stash : h->sp.grad[integrator], p, tiles, (hipStream_t)stream);
+  return launch(h, stash ? h->ks.grad_stash : h->ks.grad[integrator], p, tiles, false, (hipStream_t)stream);
 }
 
 // ---- training side --------------------------------------------------------------------------
@@ -988,7 +1018,9 @@ int phnn_rollout_trajectory(phnn_handle* h, const float* x0_dev, const float* u_
   p.traj = traj_dev;
   p.dx_out = dx_dev;
   p.no_cost = 1;
-  return launch(h, h->ks.fwd[integrator], p, (B + kTileB - 1) / kTileB, false, (hipStream_t)stream);
+  const long long tiles = (B + kTileB - 1) / kTileB;
+  if (use_split(h, tiles)) return launch_split(h, h->sp.fwd[integrator], p, tiles, (hipStream_t)stream);
+  return launch(h, h->ks.fwd[integrator], p, tiles, false, (hipStream_t)stream);
 }
 
 int phnn_rollout_wgrad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H, int32_t integrator,
@@ -1152,6 +1184,12 @@ int phnn_kernel_info(const phnn_handle* h, int32_t integrator, int32_t* rollouts
   if (!h) return PHNN_ERR_INVALID_ARG;
   (void)integrator;
   long long tiles = (B + kTileB - 1) / kTileB;
+  if (use_split(h, tiles)) {  // four waves per tile
+    if (rollouts_per_wg) *rollouts_per_wg = kTileB;
+    if (lds_bytes) *lds_bytes = (int32_t)(sizeof(float) * (size_t)h->sp.lds_floats);
+    if (n_workgroups_for_B) *n_workgroups_for_B = (int32_t)tiles;
+    return PHNN_OK;
+  }
   int waves = pick_waves(tiles, h->n_cu, h->max_waves);
   if (rollouts_per_wg) *rollouts_per_wg = waves * kTileB;
   if (lds_bytes) *lds_bytes = (int32_t)(sizeof(float) * ((size_t)h->ks.img_floats + (size_t)waves * h->ks.scr_floats));

@@ -66,6 +66,18 @@ struct GradSet {
 // defined in phnn_grad.hip
 bool phnn_grad_kernels(int variant, GradSet* g);
 
+// Split-tile kernels (small batches: four waves share one 16-rollout tile; phnn_kernels.hip.h "Split-tile models"),
+// defined in phnn_split.hip for the 128-wide f16x2 pHNN (fixed G) and canonical variants.  Bitwise the same results
+// and the same stash format as the whole-tile kernels.
+struct SplitSet {
+  void (*fwd[2])(RollParams);
+  void (*grad[2])(RollParams);
+  void (*fwd_stash)(RollParams);
+  void (*grad_stash)(RollParams);
+  int lds_floats;  // image + 4 x per-wave scratch + exchange area
+};
+bool phnn_split_kernels(int variant, SplitSet* g);  // false: no split-tile kernels for this variant
+
 // Weight-gradient kernels (training side), defined in phnn_wgrad.hip for the pHNN and canonical
 // variants: the adjoint kernels built with the record flag (recompute mode) and the record reduction.
 struct WgradSet {

@@ -32,11 +32,13 @@ class RolloutEngine:
     """
 
     def __init__(self, state_dict, device="cuda:0", kind=None, activation="tanh", matmul=None, force_matmul=False,
-                 max_waves=None):
+                 max_waves=None, split="auto"):
         """matmul: 'default' | 'f32' | 'bf16x3' | 'f16x2' (None: the PHNN_MATMUL environment variable, else
         'default').  The environment is read HERE, on the Python side, as a default only; the C-ABI takes the
         explicit phnn_options.  f16x2 on a model narrower than 128 needs force_matmul=True (known to exceed the
-        stated tolerance there).  max_waves (None: PHNN_MAX_WAVES, else 8): waves per workgroup cap."""
+        stated tolerance there).  max_waves (None: PHNN_MAX_WAVES, else 8): waves per workgroup cap.
+        split: 'auto' | 'never' | 'always' -- the small-batch kernels that put four waves on every 16-rollout tile
+        (bitwise the same results; automatic while the batch has at most two tiles per CU)."""
         self.lib = _capi.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -58,6 +60,9 @@ class RolloutEngine:
         self.options.matmul_mode = _capi.MATMUL_MODES[matmul]
         self.options.force_matmul = int(bool(force_matmul))
         self.options.max_waves = int(max_waves)
+        if split not in _capi.SPLIT_MODES:
+            raise ValueError(f"split must be one of {sorted(_capi.SPLIT_MODES)}, got {split!r}")
+        self.options.split_tiles = _capi.SPLIT_MODES[split]
         # K1 -> K2 activation stash (Euler): on unless PHNN_NO_STASH=1; capped so a huge batch falls back to
         # the recompute kernels instead of allocating more than max_stash_bytes of HBM
         self.use_stash = os.environ.get("PHNN_NO_STASH", "0") != "1"

@@ -85,6 +85,23 @@ def main():
     t = timed(lambda: eng.rollout_cost_grad(x0, U, pend, "rk4", 0.05, workspace=ws), reps=2, warm=1)
     out.append({"config": "5: ODEFunc(2,1), rk4, H=200, B=65536, K1+K2", "ms": round(t * 1e3, 3),
                 "rollouts_grads_per_s": round(65536 / t, 1)})
+    # training side: forward rollout + adjoint with records + record reduction -> d loss / d theta
+    for name, n, H, B, dt in (("phnn_cartpole", 4, 20, 4096, 0.02), ("phnn_cartpole", 4, 50, 65536, 0.02),
+                              ("canonical_cartpole", 4, 20, 4096, 0.02)):
+        eng = RolloutEngine(weights(name), dev)
+        x0, U = [torch.tensor(a, device=dev) for a in inputs(n, B, H, 5.0)]
+        tb = torch.randn(B, H + 1, n, device=dev)
+
+        def train_pass():
+            traj = eng.rollout_trajectory(x0, U, "euler", dt)
+            eng.rollout_wgrad(x0, U, traj, "euler", dt, traj_bar=tb)
+
+        t = timed(train_pass, reps=5, warm=2)
+        # algorithmic FLOPs per rollout-step: forward 73.0 k + VJP 74.2 k + the parameter outer products:
+        # 2 x 2 x 128 x 128 (W2) + 2 x 16 x 128 (V2) + small = 69.9 k
+        out.append({"config": f"f4: {name} training pass (rollout + parameter gradient), euler, H={H}, B={B}",
+                    "ms": round(t * 1e3, 3), "rollouts_wgrads_per_s": round(B / t, 1),
+                    "record_bytes_per_rollout_step": eng.lib.phnn_wgrad_workspace_bytes(eng.h, 16, 1, 0) // 16})
     for o in out:
         print(json.dumps(o))
 
