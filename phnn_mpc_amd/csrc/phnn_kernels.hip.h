@@ -624,10 +624,10 @@ struct LayH1 {  // in(<=4) -> HID -> out(<=16)  (R_net, G_net)
 //        3 qd raw        W2^T of the -gdot2/2 the kernel forms, un-normalised (= -S Sb k1 qd / 2)
 //        4 hbR           R_net: (V2^T rbar) (1 - h^2)      (pHNN only)
 //        5 hbG           G_net: (V2^T gbar) (1 - h^2)      (learned G only)
-//   then 16 rollouts x kRecSmall floats: x[4] (H_net input), v[4], lam[4], dH[4], rbar[16], u, Hbar, pad[2]
+//   then 16 rollouts x kRecSmall floats: x[4] (H_net input), v[4], lam[4], dH[4], rbar[16], u[4], Hbar, pad[3]
 // (S, Sb, k1: power-of-two / tanh-constant scales folded into the image, LayH2::oB3.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kRecSmall = 36;
+constexpr int kRecSmall = 40;
 template <int T, int NBIG>
 struct WRec {
   static constexpr int VEC = T * 256;
@@ -909,24 +909,25 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
 // ------------------------------------------------------------------------------------------------
 // Model: pHNN (src/pHNN.py:52-100)
 // ------------------------------------------------------------------------------------------------
-template <int N_, int HID_, bool FIXG_, int MM_ = MM_F32>
+template <int N_, int HID_, bool FIXG_, int MM_ = MM_F32, int MI_ = 1>
 struct PhnnModel {
-  static constexpr int N = N_, HID = HID_, T = HID / 16, MM = MM_;
+  static constexpr int N = N_, HID = HID_, T = HID / 16, MM = MM_, MI = MI_;  // MI = input_dim m (controls per step)
   static constexpr bool FIXG = FIXG_, SPLIT = false;
+  static_assert(N_ * MI_ <= 16 && MI_ <= 4, "G_net output n*m <= 16, m <= 4");
   static constexpr int SCR = kScrFloats;  // per-wave LDS scratch (exchange of the 16 R_net / G_net outputs)
   static constexpr int oH = 0;
   static constexpr int oR = oH + LayH2<HID, MM>::SIZE;
   static constexpr int oGn = oR + LayH1<HID, MM>::SIZE;
   static constexpr int oJ = oGn + (FIXG ? 0 : LayH1<HID, MM>::SIZE);  // [16] J - J^T, row-major N x N
-  static constexpr int oG = oJ + 16;                               // [4]  G_fixed (m = 1)
-  static constexpr int IMG = oG + 4;
+  static constexpr int oG = oJ + 16;                               // [16] G_fixed, row-major N x MI
+  static constexpr int IMG = oG + 16;
 
   // floats one wave stashes per step for the adjoint: a2, q1 (T x 256 each) + dH (16 x 4); a1 is recomputed
   static constexpr int STASH = 2 * T * 256 + 64;
 
   // dx = (Jeff - S S^T) dH + G u, with S = sym(R_raw).  stash != null: keep the H_net tape for K2.
   template <bool WANT_H, bool ST = false>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, f32x4 u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     HTape<HID> tp;
     f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, x, tp, Hval);
@@ -938,21 +939,21 @@ struct PhnnModel {
     Act<T> hR;
     float rf[16];
     h1_fwd<HID, MM>(L + oR, scr, ln, x, hR, rf);
-    float G[N];
+    float G[N * MI];  // G(x) row-major (N, MI): G_fixed buffer or G_net(x).view(n, m)  (src/pHNN.py:86-92)
     if (FIXG) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) G[i] = L[oG + i];
+      for (int i = 0; i < N * MI; ++i) G[i] = L[oG + i];
     } else {
       Act<T> hG;
       float gf[16];
       h1_fwd<HID, MM>(L + oGn, scr, ln, x, hG, gf);
 #pragma unroll
-      for (int i = 0; i < N; ++i) G[i] = gf[i];
+      for (int i = 0; i < N * MI; ++i) G[i] = gf[i];
     }
     return combine(L, rf, dH, G, u);
   }
 
-  DEV static f32x4 combine(const float* L, const float (&rf)[16], f32x4 dH, const float (&G)[N], float u) {
+  DEV static f32x4 combine(const float* L, const float (&rf)[16], f32x4 dH, const float (&G)[N * MI], f32x4 u) {
     float S[N][N], StdH[N];
 #pragma unroll
     for (int i = 0; i < N; ++i)
@@ -973,7 +974,14 @@ struct PhnnModel {
       for (int j = 0; j < N; ++j) acc = __builtin_fmaf(L[oJ + i * N + j], dH[j], acc);
 #pragma unroll
       for (int k = 0; k < N; ++k) acc = __builtin_fmaf(-S[i][k], StdH[k], acc);
-      dx[i] = __builtin_fmaf(G[i], u, acc);
+      if (MI == 1) {
+        dx[i] = __builtin_fmaf(G[i], u[0], acc);
+      } else {  // acc + sum_k G[i][k] u_k, the G u product formed first as bmm does (src/pHNN.py:97)
+        float gu = 0.f;
+#pragma unroll
+        for (int k = 0; k < MI; ++k) gu = __builtin_fmaf(G[i * MI + k], u[k], gu);
+        dx[i] = acc + gu;
+      }
     }
     return dx;
   }
@@ -985,7 +993,7 @@ struct PhnnModel {
   // xbar = (df/dx)^T lam, ubar = (df/du)^T lam at (x,u); recomputes the forward tape it needs.
   // WG: also writes the weight-gradient record of this evaluation to `rec` (Hbar = cotangent on H, adds Hbar dH to xbar).
   template <bool ST = false, bool WG = false>
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar,
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, f32x4 u, f32x4 lam, f32x4& xbar, f32x4& ubar,
                       const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     keep_lds_reads_local();
     HTape<HID> tp;
@@ -1043,10 +1051,12 @@ struct PhnnModel {
         for (int k = 0; k < 4; ++k) sm[4 + k] = f32x4{rbar[4 * k], rbar[4 * k + 1], rbar[4 * k + 2], rbar[4 * k + 3]};
       }
     }
-    ubar = 0.f;
+    ubar = splat4(0.f);
     if (FIXG) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) ubar = __builtin_fmaf(L[oG + i], lam[i], ubar);
+      for (int k = 0; k < MI; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) ubar[k] = __builtin_fmaf(L[oG + i * MI + k], lam[i], ubar[k]);
     } else {
       Act<T> hG;
       float gf[16], gbar[16];
@@ -1054,10 +1064,12 @@ struct PhnnModel {
 #pragma unroll
       for (int k = 0; k < 16; ++k) gbar[k] = 0.f;
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        ubar = __builtin_fmaf(gf[i], lam[i], ubar);
-        gbar[i] = lam[i] * u;
-      }
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < MI; ++k) {
+          ubar[k] = __builtin_fmaf(gf[i * MI + k], lam[i], ubar[k]);
+          gbar[i * MI + k] = lam[i] * u[k];
+        }
       xb += h1_bwd<HID, MM, WG>(L + oGn, ln, hG, gbar, WG ? rec + 5 * Rec::VEC : nullptr);
     }
     // v = A^T lam, A = Jeff - S S^T
@@ -1077,7 +1089,8 @@ struct PhnnModel {
       sm[1] = v;
       sm[2] = lam;
       sm[3] = dH;
-      sm[8] = f32x4{u, Hbar, 0.f, 0.f};
+      sm[8] = u;
+      sm[9] = f32x4{Hbar, 0.f, 0.f, 0.f};
     }
     xbar = xb + hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
     if (WG) xbar = xbar + Hbar * dH;
@@ -1088,19 +1101,33 @@ struct PhnnModel {
 // Model: canonical pHNN with the cart-pole mass matrix (src/pHNN_canonical.py:172-273,
 // src/mass_matrix.py:270-362, src/coordinate_transforms.py:20-130)
 // ------------------------------------------------------------------------------------------------
-template <int HID_, int MM_ = MM_F32>
+template <int HID_, int MM_ = MM_F32, int MI_ = 1>
 struct CanonModel {
-  static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_;
+  static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_, MI = MI_;
   static constexpr bool SPLIT = false;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int oH = 0;
-  static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // [16]: a, b, c, 0, Rd[4], G[4], sigmoid(R_diag_raw)[4]
-  static constexpr int IMG = oC + 16;
+  static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // a, b, c, 0 | Rd[4] | sigmoid(R_diag_raw)[4] | G[4][MI] (16 slots)
+  static constexpr int oCG = oC + 12;
+  static constexpr int IMG = oC + 28;
+
+  DEV static float Base_Gu(const float* L, int row, f32x4 u) {  // (G u)_row
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MI; ++k) s = __builtin_fmaf(L[oCG + row * MI + k], u[k], s);
+    return s;
+  }
+  DEV static f32x4 Base_Gt(const float* L, float dpb0, float dpb1) {  // G^T [0, 0, dpb0, dpb1]: only the dp rows reach the output
+    f32x4 ub = splat4(0.f);
+#pragma unroll
+    for (int k = 0; k < MI; ++k) ub[k] = L[oCG + 2 * MI + k] * dpb0 + L[oCG + 3 * MI + k] * dpb1;
+    return ub;
+  }
 
   static constexpr int STASH = 2 * T * 256 + 64;
 
   template <bool WANT_H, bool ST = false>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, float u, float& Hval, float* stash = nullptr) {
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, f32x4 u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
     float sn, cs;
@@ -1114,8 +1141,8 @@ struct CanonModel {
       store_act<T>(stash + T * 256, ln, tp.q1);
       if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
     }
-    float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + L[oC + 10] * u;
-    float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + L[oC + 11] * u;
+    float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + Base_Gu(L, 2, u);
+    float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + Base_Gu(L, 3, u);
     float det = (a * c - bc * bc) + 1e-6f;
     float mi00 = c / det, mi01 = -bc / det, mi11 = a / det;
     return f32x4{mi00 * z[2] + mi01 * z[3], mi01 * z[2] + mi11 * z[3], mi00 * dp0 + mi01 * dp1,
@@ -1127,7 +1154,7 @@ struct CanonModel {
 
   // WG: also writes the weight-gradient record (a2, q1, ad2, qd; small: z, v, lam, dH, the two R_diag cotangents)
   template <bool ST = false, bool WG = false>
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, float u, f32x4 lam, f32x4& ybar, float& ubar,
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, f32x4 u, f32x4 lam, f32x4& ybar, f32x4& ubar,
                       const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     keep_lds_reads_local();
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
@@ -1147,8 +1174,8 @@ struct CanonModel {
       dH = hnet_grad<HID, false, MM>(L + oH, ln, z, tp, Hdummy);
     }
     float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
-    float dp0 = (-dH[0] - Rd2 * dH[2]) + L[oC + 10] * u;
-    float dp1 = (-dH[1] - Rd3 * dH[3]) + L[oC + 11] * u;
+    float dp0 = (-dH[0] - Rd2 * dH[2]) + Base_Gu(L, 2, u);
+    float dp1 = (-dH[1] - Rd3 * dH[3]) + Base_Gu(L, 3, u);
     float det = (a * c - bc * bc) + 1e-6f;
     float rdet = 1.0f / det;
     float mi00 = c * rdet, mi01 = -bc * rdet, mi11 = a * rdet;
@@ -1158,7 +1185,7 @@ struct CanonModel {
     float mb01 = lam[0] * z[3] + lam[1] * z[2] + lam[2] * dp1 + lam[3] * dp0;
     float mb11 = lam[1] * z[3] + lam[3] * dp1;
     f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
-    ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
+    ubar = Base_Gt(L, dpb0, dpb1);
     if (WG) {
       store_rec<T>(rec, ln, tp.a2);
       store_rec<T>(rec + Rec::VEC, ln, tp.q1);
@@ -1170,7 +1197,8 @@ struct CanonModel {
         sm[3] = dH;
         // d(lam^T f)/d Rd_{2,3}: dp_i = -dH_i - Rd_{2+i} dH_{2+i} + ...  (softplus' is applied by the reduce kernel)
         sm[4] = f32x4{0.f, 0.f, -dpb0 * dH[2], -dpb1 * dH[3]};
-        sm[8] = f32x4{u, Hbar, 0.f, 0.f};
+        sm[8] = u;
+        sm[9] = f32x4{Hbar, 0.f, 0.f, 0.f};
       }
     }
     f32x4 zb = hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
@@ -1399,7 +1427,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
   using Base = PhnnModel<N_, 128, true, MM_F16X2>;
   static constexpr int N = N_, HID = 128, T = 8, MM = MM_F16X2;
   static constexpr bool FIXG = true, SPLIT = true;
-  static constexpr int SCR = Base::SCR, IMG = Base::IMG, STASH = Base::STASH;
+  static constexpr int SCR = Base::SCR, IMG = Base::IMG, STASH = Base::STASH, MI = 1;
   static constexpr int oH = Base::oH, oR = Base::oR, oJ = Base::oJ, oG = Base::oG;
   using YR = LayH1<128, MM_F16X2>;
 
@@ -1422,7 +1450,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
   }
 
   template <bool WANT_H, bool ST = false>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, f32x4 u, float& Hval, float* stash = nullptr) {
     static_assert(!WANT_H, "the split-tile kernels are rollout kernels");
     keep_lds_reads_local();
     HTapeW tp;
@@ -1445,7 +1473,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
   }
 
   template <bool ST = false, bool WG = false>
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar,
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, f32x4 u, f32x4 lam, f32x4& xbar, f32x4& ubar,
                       const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     static_assert(!WG, "weight-gradient records come from the whole-tile kernels");
     keep_lds_reads_local();
@@ -1519,9 +1547,9 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
       keep_lds_reads_local();
       PR = to4_group<2>(L + oR + YR::oV1T + (ln.i & 3) * YR::LR + 16 * t0, ln, hb.v);
     }
-    ubar = 0.f;
+    ubar = splat4(0.f);
 #pragma unroll
-    for (int i = 0; i < N; ++i) ubar = __builtin_fmaf(L[oG + i], lam[i], ubar);
+    for (int i = 0; i < N; ++i) ubar[0] = __builtin_fmaf(L[oG + i], lam[i], ubar[0]);
     f32x4 v = splat4(0.f);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -1548,10 +1576,12 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
   using Base = CanonModel<128, MM_F16X2>;
   static constexpr int N = 4, HID = 128, T = 8, MM = MM_F16X2;
   static constexpr bool SPLIT = true;
-  static constexpr int SCR = 0, IMG = Base::IMG, STASH = Base::STASH, oH = Base::oH, oC = Base::oC;
+  static constexpr int SCR = 0, IMG = Base::IMG, STASH = Base::STASH, oH = Base::oH, oC = Base::oC, MI = 1;
+  DEV static float Base_Gu(const float* L, int row, f32x4 u) { return Base::Base_Gu(L, row, u); }
+  DEV static f32x4 Base_Gt(const float* L, float dpb0, float dpb1) { return Base::Base_Gt(L, dpb0, dpb1); }
 
   template <bool WANT_H, bool ST = false>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, float u, float& Hval, float* stash = nullptr) {
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, f32x4 u, float& Hval, float* stash = nullptr) {
     static_assert(!WANT_H, "the split-tile kernels are rollout kernels");
     keep_lds_reads_local();
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
@@ -1569,8 +1599,8 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
     __syncthreads();
     f32x4 dH = xch_sum_partials(ln.xch + kXP0, ln);
     if (ST && ln.q == 0 && ln.w == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
-    float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + L[oC + 10] * u;
-    float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + L[oC + 11] * u;
+    float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + Base_Gu(L, 2, u);
+    float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + Base_Gu(L, 3, u);
     float det = (a * c - bc * bc) + 1e-6f;
     float mi00 = c / det, mi01 = -bc / det, mi11 = a / det;
     return f32x4{mi00 * z[2] + mi01 * z[3], mi01 * z[2] + mi11 * z[3], mi00 * dp0 + mi01 * dp1,
@@ -1578,7 +1608,7 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
   }
 
   template <bool ST = false, bool WG = false>
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, float u, f32x4 lam, f32x4& ybar, float& ubar,
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, f32x4 u, f32x4 lam, f32x4& ybar, f32x4& ubar,
                       const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     static_assert(!WG, "weight-gradient records come from the whole-tile kernels");
     keep_lds_reads_local();
@@ -1605,8 +1635,8 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
       dH = xch_sum_partials(ln.xch + kXP0, ln);
     }
     float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
-    float dp0 = (-dH[0] - Rd2 * dH[2]) + L[oC + 10] * u;
-    float dp1 = (-dH[1] - Rd3 * dH[3]) + L[oC + 11] * u;
+    float dp0 = (-dH[0] - Rd2 * dH[2]) + Base_Gu(L, 2, u);
+    float dp1 = (-dH[1] - Rd3 * dH[3]) + Base_Gu(L, 3, u);
     float det = (a * c - bc * bc) + 1e-6f;
     float rdet = 1.0f / det;
     float mi00 = c * rdet, mi01 = -bc * rdet, mi11 = a * rdet;
@@ -1616,7 +1646,7 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
     float mb01 = lam[0] * z[3] + lam[1] * z[2] + lam[2] * dp1 + lam[3] * dp0;
     float mb11 = lam[1] * z[3] + lam[3] * dp1;
     f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
-    ubar = L[oC + 10] * dpb0 + L[oC + 11] * dpb1;
+    ubar = Base_Gt(L, dpb0, dpb1);
     float scaleH;
     f32x4 PH = hnet_hvp_w(L + oH, ln, tp, v, scaleH);
     xch_put_partial(ln.xch + kXP1, ln, PH);
@@ -1637,7 +1667,7 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
 // ------------------------------------------------------------------------------------------------
 template <int N_, int HID_, int MM_ = MM_F32>
 struct OdeModel {
-  static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8, MM = MM_;
+  static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8, MM = MM_, MI = 1;
   static constexpr bool SPLIT = false;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int WF = MM == MM_F16X2 ? HfImg<HID>::FLOATS : HID * LD;  // one hidden x hidden image
@@ -1716,7 +1746,8 @@ struct OdeModel {
   static constexpr int STASH = 2 * T * 256;
 
   template <bool WANT_H, bool ST = false>
-  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, float u, float& Hval, float* stash = nullptr) {
+  DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, f32x4 uv, float& Hval, float* stash = nullptr) {
+    const float u = uv[0];
     Tape tp;
     if (WANT_H) Hval = 0.f;
     f32x4 dx = fwd(L, ln, x, u, tp);
@@ -1727,9 +1758,12 @@ struct OdeModel {
     return dx;
   }
 
-  template <bool ST = false>
-  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, float u, f32x4 lam, f32x4& xbar, float& ubar,
-                      const float* stash = nullptr) {
+  template <bool ST = false, bool WG = false>
+  DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 x, f32x4 uv, f32x4 lam, f32x4& xbar, f32x4& ubar4,
+                      const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
+    static_assert(!WG, "ODEFunc has no weight-gradient kernels");
+    const float u = uv[0];
+    float ubar;
     Tape tp;
     if (ST) {
       load_act<T>(stash, ln, tp.a2);
@@ -1768,6 +1802,7 @@ struct OdeModel {
       inb[N & 3] = 0.f;
     }
     xbar = inb;
+    ubar4 = f32x4{ubar, 0.f, 0.f, 0.f};
   }
 };
 
@@ -1890,6 +1925,35 @@ DEV void store_state(float* p, f32x4 x) {
 
 DEV float clamp_u(const phnn_cost& c, float u) { return c.has_u_bounds ? fminf(fmaxf(u, c.u_min), c.u_max) : u; }
 
+// controls of one step: (B,H,MI) row-major, up = this rollout's (H,MI) block
+template <int MI>
+DEV f32x4 load_u(const float* up, int t) {
+  f32x4 u = splat4(0.f);
+#pragma unroll
+  for (int k = 0; k < MI; ++k) u[k] = up[t * MI + k];
+  return u;
+}
+template <int MI>
+DEV f32x4 clamp_u4(const phnn_cost& c, f32x4 u) {
+#pragma unroll
+  for (int k = 0; k < MI; ++k) u[k] = clamp_u(c, u[k]);
+  return u;
+}
+// u^T R u in the order of ((u @ R) * u).sum() (src/mpc_controller_canonical.py:116-118); m = 1: (u R) u
+template <int MI>
+DEV float control_cost(const phnn_cost& c, f32x4 u) {
+  if (MI == 1) return (u[0] * c.R[0]) * u[0];
+  float cost = 0.f;
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) s = __builtin_fmaf(u[i], c.R[i * MI + j], s);
+    cost = __builtin_fmaf(s, u[j], cost);
+  }
+  return cost;
+}
+
 // K1: forward march.  One wave = 16 rollouts; grid x = ceil(B/16/waves).
 template <class M, int INTEG, bool STASH>
 __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
@@ -1915,11 +1979,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   const bool writer = valid && ln.q == 0 && (!M::SPLIT || wave == 0);
   if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1)) * N, x);
   float cost = state_cost<N>(p.c, x);
-  const float* up = p.u + b * p.H;
+  constexpr int MI = M::MI;
+  const float* up = p.u + b * p.H * MI;
   float Hd;
   for (int t = 0; t < p.H; ++t) {
-    float u = clamp_u(p.c, up[t]);
-    cost = __builtin_fmaf(u * p.c.R[0], u, cost);
+    f32x4 u = clamp_u4<MI>(p.c, load_u<MI>(up, t));
+    if (MI == 1) cost = __builtin_fmaf(u[0] * p.c.R[0], u[0], cost);
+    else cost += control_cost<MI>(p.c, u);
     f32x4 k1 = M::template f<false, STASH>(L, scr, ln, x, u, Hd,
                                            STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr);
     if (p.dx_out && writer) store_state<N>(p.dx_out + (b * p.H + t) * N, k1);
@@ -1960,7 +2026,8 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   const float* L = lds;
   const bool writer = valid && ln.q == 0 && (!M::SPLIT || wave == 0);
   const float* tr = p.traj_in + (b * (p.H + 1)) * N;
-  const float* up = p.u + b * p.H;
+  constexpr int MI = M::MI;
+  const float* up = p.u + b * p.H * MI;
   const float cb = p.no_cost ? 0.0f : (p.cost_bar ? p.cost_bar[b] : 1.0f);
   const float* tb = p.traj_bar ? p.traj_bar + (b * (p.H + 1)) * N : nullptr;
   const float* db = p.dx_bar ? p.dx_bar + (b * p.H) * N : nullptr;
@@ -1973,12 +2040,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   float Hd;
   for (int t = p.H - 1; t >= 0; --t) {
     f32x4 x = load_state<N>(tr + (long long)t * N);
-    float uraw = up[t];
-    float u = p.no_cost ? uraw : clamp_u(p.c, uraw);
+    const f32x4 uraw = load_u<MI>(up, t);
+    const f32x4 u = p.no_cost ? uraw : clamp_u4<MI>(p.c, uraw);
     f32x4 dxb = splat4(0.f);
     if (db) dxb = load_state<N>(db + (long long)t * N) * live;
-    f32x4 xb;
-    float ub, utot;
+    f32x4 xb, ub, utot;
     float* rec = nullptr;
     if constexpr (WG) rec = p.wrec + ((tile * p.H + t) * STAGES) * (long long)M::Rec::SIZE;
     if (INTEG == PHNN_INTEG_EULER) {
@@ -2024,9 +2090,20 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
     }
     lam = lam + cb * state_cost_grad<N>(p.c, x);
     if (tb) lam = lam + load_state<N>(tb + (long long)t * N) * (WG ? live : 1.0f);
-    float g = __builtin_fmaf(cb * (2.0f * p.c.R[0]), u, utot);
-    if (!p.no_cost && p.c.has_u_bounds && !(uraw >= p.c.u_min && uraw <= p.c.u_max)) g = 0.f;
-    if (writer && p.grad_u) p.grad_u[b * p.H + t] = g;
+#pragma unroll
+    for (int k = 0; k < MI; ++k) {
+      float g;
+      if (MI == 1) {
+        g = __builtin_fmaf(cb * (2.0f * p.c.R[0]), u[0], utot[0]);
+      } else {  // d(u^T R u)/du_k = sum_j (R[k][j] + R[j][k]) u_j
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MI; ++j) s = __builtin_fmaf(p.c.R[k * MI + j] + p.c.R[j * MI + k], u[j], s);
+        g = __builtin_fmaf(cb, s, utot[k]);
+      }
+      if (!p.no_cost && p.c.has_u_bounds && !(uraw[k] >= p.c.u_min && uraw[k] <= p.c.u_max)) g = 0.f;
+      if (writer && p.grad_u) p.grad_u[(b * p.H + t) * MI + k] = g;
+    }
   }
   if (p.grad_x0 && writer) store_state<N>(p.grad_x0 + b * N, lam);
 }
@@ -2052,7 +2129,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_forward(PointParams p)
     if (!valid) b = p.B - 1;
     f32x4 x = load_state<N>(p.x + b * N);
     float Hval = 0.f;
-    f32x4 dx = M::template f<true>(lds, scr, ln, x, p.u[b], Hval);
+    f32x4 dx = M::template f<true>(lds, scr, ln, x, load_u<M::MI>(p.u + b * M::MI, 0), Hval);
     if (valid && ln.q == 0) {
       store_state<N>(p.dx + b * N, dx);
       if (p.Hout) p.Hout[b] = Hval;
@@ -2080,18 +2157,19 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_model_vjp(PointParams p) {
     if (!valid) b = p.B - 1;
     f32x4 x = load_state<N>(p.x + b * N);
     f32x4 lam = load_state<N>(p.lam + b * N);
-    f32x4 xb;
-    float ub;
+    f32x4 xb, ub;
+    const f32x4 u = load_u<M::MI>(p.u + b * M::MI, 0);
     if constexpr (WG) {  // padding lanes carry zero cotangents: they add nothing to the weight gradient
       const float live = valid ? 1.0f : 0.0f;
-      M::template vjp<false, true>(lds, scr, ln, x, p.u[b], lam * live, xb, ub, nullptr,
+      M::template vjp<false, true>(lds, scr, ln, x, u, lam * live, xb, ub, nullptr,
                                    p.wrec + tile * (long long)M::Rec::SIZE, p.Hbar ? p.Hbar[b] * live : 0.0f);
     } else {
-      M::vjp(lds, scr, ln, x, p.u[b], lam, xb, ub);
+      M::vjp(lds, scr, ln, x, u, lam, xb, ub);
     }
     if (valid && ln.q == 0) {
       store_state<N>(p.dx + b * N, xb);
-      p.Hout[b] = ub;
+#pragma unroll
+      for (int k = 0; k < M::MI; ++k) p.Hout[b * M::MI + k] = ub[k];
     }
   }
 }
@@ -2159,25 +2237,25 @@ struct BlobH {  // in(N) -> HID -> HID -> 1
 
 template <class M>
 struct BlobOf;
-template <int N, int HID, bool FIXG, int MM>
-struct BlobOf<PhnnModel<N, HID, FIXG, MM>> {
+template <int N, int HID, bool FIXG, int MM, int MI>
+struct BlobOf<PhnnModel<N, HID, FIXG, MM, MI>> {
   static constexpr int oJ = 0, oGfix = N * N;
-  static constexpr BlobMlp1<N, HID> R{N * N + (FIXG ? N : 0), N * N};
+  static constexpr BlobMlp1<N, HID> R{N * N + (FIXG ? N * MI : 0), N * N};
   static constexpr BlobH<N, HID> H{R.oV1 + R.size};
-  static constexpr BlobMlp1<N, HID> G{H.oW1 + H.size, N};
+  static constexpr BlobMlp1<N, HID> G{H.oW1 + H.size, N * MI};
   static constexpr int SIZE = H.oW1 + H.size + (FIXG ? 0 : G.size);
 };
-template <int HID, int MM>
-struct BlobOf<CanonModel<HID, MM>> {
-  static constexpr int oRd = 0;  // R_diag_raw (4) | G (4) | log_a, b, log_c | H_net
-  static constexpr BlobH<4, HID> H{4 + 4 + 3};
+template <int HID, int MM, int MI>
+struct BlobOf<CanonModel<HID, MM, MI>> {
+  static constexpr int oRd = 0;  // R_diag_raw (4) | G (4 MI) | log_a, b, log_c | H_net
+  static constexpr BlobH<4, HID> H{4 + 4 * MI + 3};
   static constexpr int SIZE = H.oW1 + H.size;
 };
 
 template <class M>
 struct IsPhnn { static constexpr bool value = false; };
-template <int N, int HID, bool FIXG, int MM>
-struct IsPhnn<PhnnModel<N, HID, FIXG, MM>> { static constexpr bool value = true; };
+template <int N, int HID, bool FIXG, int MM, int MI>
+struct IsPhnn<PhnnModel<N, HID, FIXG, MM, MI>> { static constexpr bool value = true; };
 
 // one-hidden-layer net (R_net / G_net) part of a record, for the units of this lane.  NOUT used outputs.
 template <int N, int HID, int MM, int NOUT>
@@ -2268,7 +2346,7 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   f32x4 aW3 = splat4(0.f), aB2 = splat4(0.f), aB1 = splat4(0.f), aW1[4] = {};
   float aB3 = 0.f, aJ[N * N] = {}, aRd[2] = {};
   H1Acc<N, HID, MM, PHNN ? N * N : 1> accR;
-  H1Acc<N, HID, MM, N> accG;
+  H1Acc<N, HID, MM, N * M::MI> accG;
 
   int buf = 0;
   for (long long r = blockIdx.x; r < p.n_rec; r += gridDim.x, buf ^= 1) {
@@ -2276,8 +2354,8 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     const f32x4* big = reinterpret_cast<const f32x4*>(R) + w * 64 + ln.lane;
     const f32x4 a2 = big[0], q1r = big[Rec::VEC / 4], ad2r = big[2 * (Rec::VEC / 4)], qdr = big[3 * (Rec::VEC / 4)];
     const f32x4* sm = reinterpret_cast<const f32x4*>(R + Rec::oSmall + ln.i * kRecSmall);
-    const f32x4 x = sm[0], v = sm[1], lam = sm[2], dH = sm[3], misc = sm[8];
-    const float Hbar = misc[1];
+    const f32x4 x = sm[0], v = sm[1], lam = sm[2], dH = sm[3], uu = sm[8];
+    const float Hbar = sm[9][0];
     // H_net factors of this lane's 4 units
     const f32x4 a1 = tanh4_model<T>(mfma(w1f, sel4(x, ln.q), b1v));
     const f32x4 d1 = dtanh(a1), d2 = dtanh(a2);
@@ -2317,9 +2395,11 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
       }
       accR.add(L + M::oR, w, ln, x, big[4 * (Rec::VEC / 4)], rbar);
       if constexpr (!M::FIXG) {
-        float gbar[N];
+        float gbar[N * M::MI];
 #pragma unroll
-        for (int i = 0; i < N; ++i) gbar[i] = lam[i] * misc[0];
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+          for (int k = 0; k < M::MI; ++k) gbar[i * M::MI + k] = lam[i] * uu[k];
         accG.add(L + M::oGn, w, ln, x, big[5 * (Rec::VEC / 4)], gbar);
       }
     }
@@ -2391,8 +2471,8 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     if (w == 0 && ln.lane == 0) {
       row[BL::oRd + 0] = 0.f;  // rows 0, 1 of R multiply the dq rows the reference discards: zero gradient
       row[BL::oRd + 1] = 0.f;
-      row[BL::oRd + 2] = t2 * L[M::oC + 14];
-      row[BL::oRd + 3] = t3 * L[M::oC + 15];
+      row[BL::oRd + 2] = t2 * L[M::oC + 10];
+      row[BL::oRd + 3] = t3 * L[M::oC + 11];
     }
   }
 }

@@ -132,9 +132,20 @@ int pick_variant(const phnn_desc* d, const phnn_options& opt, std::string* why) 
       return V_NONE;
     }
   }
-  if (d->m != 1) {
-    snprintf(buf, sizeof buf, "input_dim m=%d: the gfx950 kernels are instantiated for m=1 only", d->m);
+  if (d->m > PHNN_SUPPORTED_M) {
+    snprintf(buf, sizeof buf, "input_dim m=%d: the gfx950 kernels are instantiated for m <= %d", d->m, PHNN_SUPPORTED_M);
     *why = buf;
+    return V_NONE;
+  }
+  if (d->m == 2) {  // two controls: 128-wide f16x2 kernels of the cart-pole-sized models (n = 4); narrower nets are zero-padded
+    const int hid = d->h_net.hidden[0];
+    const bool f16 = matmul_mode(opt, 128) == MM_F16X2;
+    if (f16 && d->kind == PHNN_MODEL_PHNN && d->n == 4 && hid == 128 && same_hidden(d->h_net, 2, 128) &&
+        same_hidden(d->r_net, 1, 128) && (d->fixed_G || same_hidden(d->g_net, 1, 128)))
+      return d->fixed_G ? V_PHNN_4_128_FIX_H_M2 : V_PHNN_4_128_GNET_H_M2;
+    if (f16 && d->kind == PHNN_MODEL_CANONICAL && d->n == 4 && same_hidden(d->h_net, 2, 128)) return V_CANON_128_H_M2;
+    *why = "input_dim m=2: kernels exist for the pHNN (n=4, fixed or learned G) and the canonical pHNN, hidden widths up "
+           "to 128, f16x2 products";
     return V_NONE;
   }
   if (d->kind == PHNN_MODEL_PHNN) {
@@ -381,14 +392,14 @@ void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
   img.assign(M::IMG, 0.f);
   const float* J = p; p += N * N;
   const float* G = nullptr;
-  if (d->fixed_G) { G = p; p += N; }
+  if (d->fixed_G) { G = p; p += N * M::MI; }
   p = pack_h1<HID, M::MM>(img.data() + M::oR, p, N, N * N);
   p = pack_h2<HID, M::MM>(img.data() + M::oH, p, N);
-  if (!d->fixed_G) p = pack_h1<HID, M::MM>(img.data() + M::oGn, p, N, N);
+  if (!d->fixed_G) p = pack_h1<HID, M::MM>(img.data() + M::oGn, p, N, N * M::MI);
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) img[M::oJ + i * N + j] = J[i * N + j] - J[j * N + i];  // src/pHNN.py:83, no 1/2
   if (G)
-    for (int i = 0; i < N; ++i) img[M::oG + i] = G[i];
+    for (int i = 0; i < N * M::MI; ++i) img[M::oG + i] = G[i];  // row-major (N, MI)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -432,6 +443,7 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
   if (d->kind == PHNN_MODEL_PHNN) W = (mx <= 64 && (d->fixed_G || d->n == 2)) ? 64 : 128;
   else if (d->kind == PHNN_MODEL_CANONICAL) W = mx <= 64 ? 64 : 128;
   else W = (d->n == 2 && mx <= 64) ? 64 : 128;
+  if (d->m > 1) W = 128;  // the m = 2 kernels exist at width 128 only
   if (mx > W || mx < 1) {
     char buf[160];
     snprintf(buf, sizeof buf, "hidden width %d exceeds the widest kernel (%d) for this model family / state dimension", mx, W);
@@ -520,7 +532,7 @@ void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
   constexpr int HID = M::HID;
   img.assign(M::IMG, 0.f);
   const float* Rd = p; p += 4;
-  const float* G = p; p += 4;
+  const float* G = p; p += 4 * M::MI;
   float log_a = p[0], b = p[1], log_c = p[2];
   p += 3;
   p = pack_h2<HID, M::MM>(img.data() + M::oH, p, 4);
@@ -529,9 +541,9 @@ void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
   c[1] = b;
   c[2] = expf(log_c) + 1e-3f;
   for (int i = 0; i < 4; ++i) c[4 + i] = softplus_host(Rd[i]) + 1e-4f;  // src/pHNN_canonical.py:162
-  for (int i = 0; i < 4; ++i) c[8 + i] = G[i];
   // softplus'(raw) = sigmoid(raw) (threshold 20 as torch.nn.functional.softplus): the weight-gradient kernels need it
-  for (int i = 0; i < 4; ++i) c[12 + i] = Rd[i] > 20.f ? 1.0f : (float)(1.0 / (1.0 + std::exp(-(double)Rd[i])));
+  for (int i = 0; i < 4; ++i) c[8 + i] = Rd[i] > 20.f ? 1.0f : (float)(1.0 / (1.0 + std::exp(-(double)Rd[i])));
+  for (int i = 0; i < 4 * M::MI; ++i) c[12 + i] = G[i];  // row-major (4, MI)
 }
 
 template <class M>
@@ -602,6 +614,9 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_PHNN_2_64_FIX_H: pack_phnn<M_PHNN_2_64_FIX_H>(img, d, blob); break;
     case V_CANON_64_H: pack_canon<M_CANON_64_H>(img, d, blob); break;
     case V_ODE_2_64_H: pack_ode<M_ODE_2_64_H>(img, d, blob); break;
+    case V_PHNN_4_128_FIX_H_M2: pack_phnn<M_PHNN_4_128_FIX_H_M2>(img, d, blob); break;
+    case V_PHNN_4_128_GNET_H_M2: pack_phnn<M_PHNN_4_128_GNET_H_M2>(img, d, blob); break;
+    case V_CANON_128_H_M2: pack_canon<M_CANON_128_H_M2>(img, d, blob); break;
     default: break;
   }
 }

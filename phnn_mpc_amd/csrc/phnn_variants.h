@@ -30,6 +30,9 @@ enum Variant {
   V_PHNN_2_64_FIX_H,
   V_CANON_64_H,
   V_ODE_2_64_H,
+  V_PHNN_4_128_FIX_H_M2,   // two controls per step (m = 2): G is (n, 2), u is (B, H, 2)
+  V_PHNN_4_128_GNET_H_M2,
+  V_CANON_128_H_M2,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -56,6 +59,9 @@ using M_PHNN_2_64_GNET_H = PhnnModel<2, 64, false, MM_F16X2>;
 using M_PHNN_2_64_FIX_H = PhnnModel<2, 64, true, MM_F16X2>;
 using M_CANON_64_H = CanonModel<64, MM_F16X2>;
 using M_ODE_2_64_H = OdeModel<2, 64, MM_F16X2>;
+using M_PHNN_4_128_FIX_H_M2 = PhnnModel<4, 128, true, MM_F16X2, 2>;
+using M_PHNN_4_128_GNET_H_M2 = PhnnModel<4, 128, false, MM_F16X2, 2>;
+using M_CANON_128_H_M2 = CanonModel<128, MM_F16X2, 2>;
 
 struct GradSet {
   void (*grad[2])(RollParams);     // Euler, RK4: recompute the tape
@@ -118,4 +124,7 @@ hipError_t phnn_wgrad_finish(const float* slab, int rows, int PP, const int* map
   X(V_PHNN_2_64_GNET_H, M_PHNN_2_64_GNET_H, "phnn<n=2,hid=64,Gnet,f16x2>") \
   X(V_PHNN_2_64_FIX_H, M_PHNN_2_64_FIX_H, "phnn<n=2,hid=64,fixedG,f16x2>") \
   X(V_CANON_64_H, M_CANON_64_H, "canonical<hid=64,f16x2>") \
-  X(V_ODE_2_64_H, M_ODE_2_64_H, "odefunc<n=2,hid=64,f16x2>")
+  X(V_ODE_2_64_H, M_ODE_2_64_H, "odefunc<n=2,hid=64,f16x2>") \
+  X(V_PHNN_4_128_FIX_H_M2, M_PHNN_4_128_FIX_H_M2, "phnn<n=4,m=2,hid=128,fixedG,f16x2>") \
+  X(V_PHNN_4_128_GNET_H_M2, M_PHNN_4_128_GNET_H_M2, "phnn<n=4,m=2,hid=128,Gnet,f16x2>") \
+  X(V_CANON_128_H_M2, M_CANON_128_H_M2, "canonical<m=2,hid=128,f16x2>")

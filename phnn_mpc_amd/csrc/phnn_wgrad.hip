@@ -37,6 +37,9 @@ bool phnn_wgrad_kernels(int variant, WgradSet* g) {
     PHNN_WCASE(V_CANON_128, M_CANON_128)
     PHNN_WCASE(V_CANON_128_H, M_CANON_128_H)
     PHNN_WCASE(V_CANON_64, M_CANON_64)
+    PHNN_WCASE(V_PHNN_4_128_FIX_H_M2, M_PHNN_4_128_FIX_H_M2)
+    PHNN_WCASE(V_PHNN_4_128_GNET_H_M2, M_PHNN_4_128_GNET_H_M2)
+    PHNN_WCASE(V_CANON_128_H_M2, M_CANON_128_H_M2)
 #undef PHNN_WCASE
     default: return false;
   }

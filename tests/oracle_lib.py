@@ -165,3 +165,18 @@ def cost_from_golden(g, n=None, m=None, Q=None, x_target=None):
     m = int(g["m"]) if m is None else m
     return _capi.make_cost(n, m, g["Q"] if Q is None else Q, g["R"], g["x_target"] if x_target is None else x_target,
                            float(g["u_min"]), float(g["u_max"]))
+
+
+def load_m2_golden():
+    """golden_m2.npz (two control inputs): -> (arrays, {model name: state_dict})"""
+    with np.load(os.path.join(GOLDEN, "golden_m2.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    w = {}
+    for k in list(g):
+        if k.startswith("w/"):
+            _, name, key = k.split("/", 2)
+            w.setdefault(name, {})[key] = g.pop(k)
+    return g, w
+
+
+M2_MODELS = ["phnn_m2_fix", "phnn_m2_gnet", "canonical_m2"]

@@ -200,3 +200,35 @@ def test_oracle_rollout_wgrad_g16(wg, name, integ):
     assert np.abs(r["grad_u"] - wg[f"{pre}{integ}_gu_f64"]).max() <= 1e-10 * np.abs(wg[f"{pre}{integ}_gu_f64"]).max()
     assert np.abs(r["grad_x0"] - wg[f"{pre}{integ}_gx0_f64"]).max() <= 1e-10 * np.abs(wg[f"{pre}{integ}_gx0_f64"]).max()
     assert_param_grads(weights.unpack_grad_blob(w, r["grad_theta"]), wg, f"{pre}{integ}_", "f64", 1e-9, (name, integ))
+
+
+# ----------------------------------------------------------------------------- two control inputs (m = 2), row f2
+@pytest.mark.parametrize("name", ol.M2_MODELS)
+def test_oracle_two_inputs_m2(name):
+    from phnn_mpc_amd import _capi, weights
+    g, ws = ol.load_m2_golden()
+    w = ws[name]
+    m = ol.OracleModel(w, "f64")
+    assert (m.n, m.m) == (4, 2)
+    dx, H = m.forward(g[f"{name}/x"], g[f"{name}/u"])
+    assert np.allclose(dx, g[f"{name}/fwd_dx"], rtol=1e-10, atol=1e-12) and np.allclose(H, g[f"{name}/fwd_H"], rtol=1e-10, atol=1e-12)
+    xb, ub = m.vjp(g[f"{name}/x"], g[f"{name}/u"], g[f"{name}/lam"])
+    assert ub.shape == (64, 2)
+    assert np.allclose(xb, g[f"{name}/vjp_xbar"], rtol=1e-9, atol=1e-11) and np.allclose(ub, g[f"{name}/vjp_ubar"], rtol=1e-9, atol=1e-11)
+    cost = _capi.make_cost(4, 2, g[f"{name}/Q"], g[f"{name}/R"], None, -10.0, 10.0)
+    for integ in ("euler", "rk4"):
+        r = m.rollout(g[f"{name}/roll_x0"], g[f"{name}/roll_U"], cost, integ, 0.02)
+        assert np.allclose(r["traj"], g[f"{name}/roll_{integ}_traj"], rtol=1e-9, atol=1e-11)
+        assert np.allclose(r["cost"], g[f"{name}/roll_{integ}_cost"], rtol=1e-9)
+        ref = g[f"{name}/roll_{integ}_gu"]
+        assert r["grad_u"].shape == ref.shape == (6, 30, 2)
+        assert np.abs(r["grad_u"] - ref).max() <= 1e-9 * np.abs(ref).max()
+        assert np.abs(r["grad_x0"] - g[f"{name}/roll_{integ}_gx0"]).max() <= 1e-9 * np.abs(g[f"{name}/roll_{integ}_gx0"]).max()
+        U = g[f"{name}/roll_U"]
+        assert np.all(r["grad_u"][(U > 10.0) | (U < -10.0)] == 0.0)
+    gt = m.wgrad(g[f"{name}/x"], g[f"{name}/u"], g[f"{name}/lam"], g[f"{name}/Hbar"])
+    named = weights.unpack_grad_blob(w, gt)
+    for k in [k for k in g if k.startswith(f"{name}/pt_g.")]:
+        ref = g[k]
+        ours = named[k.split("pt_g.", 1)[1]].reshape(ref.shape)
+        assert np.abs(ours - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30), k
