@@ -50,6 +50,14 @@ typedef enum {
 
 typedef enum { PHNN_INTEG_EULER = 0, PHNN_INTEG_RK4 = 1 } phnn_integrator; /* src/integrators.py:13-84 */
 
+/* Mass matrix M(q) of the canonical model (src/pHNN_canonical.py:67-86 selects it from config model.mass_matrix.type):
+ *   CARTPOLE  src/mass_matrix.py:239-370  [[a, b cos th],[b cos th, c]], parameters constants to autograd, det + 1e-6
+ *   CONSTANT  src/mass_matrix.py:52-57    M = L L^T, L = tril(L_tril) with softplus(diag) + 1e-3; M^-1 = L^-T L^-1
+ *   DIAGONAL  src/mass_matrix.py:59-73    M = diag(exp(mlp(q)) + 1e-3)
+ *   FULL      src/mass_matrix.py:75-98    M = L(q) L(q)^T, L from mlp(q) (n(n+1)/2 outputs, softplus(diag) + 1e-3),
+ *                                         M^-1 = inverse of that 2x2 matrix.   q_dim = 2 (state_dim 4) only. */
+typedef enum { PHNN_MASS_CARTPOLE = 0, PHNN_MASS_CONSTANT = 1, PHNN_MASS_DIAGONAL = 2, PHNN_MASS_FULL = 3 } phnn_mass_type;
+
 /* Activation of every MLP in the model (src/NN.py:6-40 takes any nn.Module class; src/pHNN.py:41 resolves it by
  * name).  Only Tanh has kernels -- the one every shipped config selects; anything else is refused by phnn_create so
  * that a checkpoint trained with another activation (same keys, same shapes) cannot be run as a Tanh network. */
@@ -71,8 +79,10 @@ typedef struct {
  * Linear as weight (out,in) row-major followed by bias (out) -- i.e. the reference state_dict order:
  *   PHNN      : J (n*n) | G_fixed (n*m) if fixed_G | R_net layers | H_net layers | G_net layers if !fixed_G
  *               (src/pHNN.py:22-38; R_net out = n*n, H_net out = 1, G_net out = n*m)
- *   CANONICAL : R_diag_raw (n) | G (n*m) | log_a, b, log_c | H_net layers
- *               (src/pHNN_canonical.py:57-110, src/mass_matrix.py:263-268; J is the fixed canonical one)
+ *   CANONICAL : R_diag_raw (n) | G (n*m) | mass block | H_net layers
+ *               (src/pHNN_canonical.py:57-110; J is the fixed canonical one); mass block by mass_type:
+ *               CARTPOLE log_a, b, log_c (src/mass_matrix.py:263-268) | CONSTANT L_tril (q_dim*q_dim) |
+ *               DIAGONAL / FULL the layers of M_net.mlp (in q_dim, out q_dim / q_dim(q_dim+1)/2)
  *   ODEFUNC   : network layers, in = n+m, out = n (src/baseline_node.py:60-75)
  */
 typedef struct {
@@ -84,6 +94,8 @@ typedef struct {
   phnn_mlp_shape r_net; /* PHNN only */
   phnn_mlp_shape g_net; /* PHNN with fixed_G == 0 only */
   int32_t activation;   /* phnn_activation; must be PHNN_ACT_TANH */
+  int32_t mass_type;    /* CANONICAL only: phnn_mass_type */
+  phnn_mlp_shape m_net; /* CANONICAL with mass_type DIAGONAL / FULL: hidden layers of M_net.mlp */
 } phnn_desc;
 
 /* Options of phnn_create_ex; zero-initialise for the defaults. */

@@ -15,6 +15,7 @@ INTEG_EULER, INTEG_RK4 = 0, 1
 INTEGRATORS = {"euler": INTEG_EULER, "rk4": INTEG_RK4}
 
 ACT_TANH, ACT_OTHER = 0, 1
+MASS_CARTPOLE, MASS_CONSTANT, MASS_DIAGONAL, MASS_FULL = 0, 1, 2, 3
 MATMUL_MODES = {"default": 0, "f32": 1, "bf16x3": 2, "f16x2": 3}
 SPLIT_MODES = {"auto": 0, "never": 1, "always": 2}
 
@@ -49,7 +50,8 @@ class MlpShape(C.Structure):
 
 class Desc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("fixed_G", C.c_int32),
-                ("h_net", MlpShape), ("r_net", MlpShape), ("g_net", MlpShape), ("activation", C.c_int32)]
+                ("h_net", MlpShape), ("r_net", MlpShape), ("g_net", MlpShape), ("activation", C.c_int32),
+                ("mass_type", C.c_int32), ("m_net", MlpShape)]
 
 
 class Plant(C.Structure):

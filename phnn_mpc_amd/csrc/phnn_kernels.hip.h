@@ -1098,18 +1098,116 @@ struct PhnnModel {
 };
 
 // ------------------------------------------------------------------------------------------------
+// M_net.mlp of the general MassMatrixNetwork (src/mass_matrix.py:59-98): in(q_dim = 2) -> 64 -> 64 -> out (2 diagonal
+// log-entries or 3 Cholesky entries), all-f32 MFMA layers (exact f32; the net is small and not on the headline path).
+// ------------------------------------------------------------------------------------------------
+struct LayM {
+  static constexpr int HID = 64, T = 4, LD = HID + 4, LR = HID + 8;
+  static constexpr int oW1f = 0;                 // [T][64] fragment image of W1 (64 x 2)
+  static constexpr int oB1 = oW1f + T * 64;      // [64]
+  static constexpr int oW2 = oB1 + HID;          // [64][LD]
+  static constexpr int oB2 = oW2 + HID * LD;     // [64]
+  static constexpr int oWo = oB2 + HID;          // [4][LR] rows c = Wout[c,:]
+  static constexpr int oBo = oWo + 4 * LR;       // [4]
+  static constexpr int oWoTf = oBo + 4;          // [T][64] fragment image of Wout^T (64 x out)
+  static constexpr int oW1T = oWoTf + T * 64;    // [4][LR] rows c = W1[:,c]
+  static constexpr int SIZE = oW1T + 4 * LR;
+};
+
+struct MTape {
+  Act<4> a1, a2;
+  f32x4 o;
+};
+
+DEV void mnet_fwd(const float* L, Lane ln, f32x4 q, MTape& tp) {
+  using Y = LayM;
+  keep_lds_reads_local();
+  load_vec<4>(tp.a1, L + Y::oB1, ln);
+  in_layer<4>(tp.a1, L + Y::oW1f, ln, sel4(q, ln.q));
+  tanh_act<4>(tp.a1);
+  load_vec<4>(tp.a2, L + Y::oB2, ln);
+  sq_fwd<4, 4>(tp.a2, L + Y::oW2, ln, tp.a1);
+  tanh_act<4>(tp.a2);
+  tp.o = to4_rep<4>(L + Y::oWo, ln, tp.a2) + *reinterpret_cast<const f32x4*>(L + Y::oBo);
+}
+
+DEV f32x4 mnet_bwd(const float* L, Lane ln, const MTape& tp, f32x4 ob) {  // qbar = (d o / d q)^T ob
+  using Y = LayM;
+  keep_lds_reads_local();
+  Act<4> d, e;
+  zero_act<4>(d);
+  in_layer<4>(d, L + Y::oWoTf, ln, sel4(ob, ln.q));
+#pragma unroll
+  for (int t = 0; t < 4; ++t) d.v[t] = d.v[t] * dtanh(tp.a2.v[t]);
+  zero_act<4>(e);
+  sq_bwd<4, 4>(e, L + Y::oW2, ln, d);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) e.v[t] = e.v[t] * dtanh(tp.a1.v[t]);
+  return to4_rep<4>(L + Y::oW1T, ln, e);
+}
+
+DEV float softplus_dev(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch softplus, threshold 20
+DEV float sigmoid_sp_dev(float x) { return x > 20.f ? 1.0f : 1.0f / (1.0f + expf(-x)); }
+
+constexpr int MASS_CARTPOLE = 0, MASS_CONSTANT = 1, MASS_DIAGONAL = 2, MASS_FULL = 3;
+
+// M (m00, m01, m11) and M^-1 (w00, w01, w11) of MassMatrixNetwork's diagonal / full types from the mlp outputs o
+template <int MT>
+DEV void mass_from_outputs(f32x4 o, float (&m)[3], float (&w)[3]) {
+  if (MT == MASS_DIAGONAL) {  // M = diag(exp(o) + 1e-3)  (src/mass_matrix.py:157-161, 196-200)
+    m[0] = expf(o[0]) + 1e-3f;
+    m[2] = expf(o[1]) + 1e-3f;
+    m[1] = 0.f;
+    w[0] = 1.0f / m[0];
+    w[2] = 1.0f / m[2];
+    w[1] = 0.f;
+  } else {  // M = L L^T, L = [[softplus(o0) + 1e-3, 0], [o1, softplus(o2) + 1e-3]]; M^-1 = inverse of the 2x2 matrix
+    const float l00 = softplus_dev(o[0]) + 1e-3f, l10 = o[1], l11 = softplus_dev(o[2]) + 1e-3f;
+    m[0] = l00 * l00;
+    m[1] = l00 * l10;
+    m[2] = l10 * l10 + l11 * l11;
+    const float det = m[0] * m[2] - m[1] * m[1];
+    w[0] = m[2] / det;
+    w[1] = -m[1] / det;
+    w[2] = m[0] / det;
+  }
+}
+
+// cotangent of the mlp outputs from the full 2x2 cotangent Mb of M (row-major)
+template <int MT>
+DEV f32x4 mass_outputs_bar(f32x4 o, const float (&Mb)[4]) {
+  if (MT == MASS_DIAGONAL) return f32x4{Mb[0] * expf(o[0]), Mb[3] * expf(o[1]), 0.f, 0.f};
+  const float l00 = softplus_dev(o[0]) + 1e-3f, l10 = o[1], l11 = softplus_dev(o[2]) + 1e-3f;
+  const float s00 = 2.0f * Mb[0], s01 = Mb[1] + Mb[2], s11 = 2.0f * Mb[3];  // Lb = (Mb + Mb^T) L, lower triangle
+  return f32x4{(s00 * l00 + s01 * l10) * sigmoid_sp_dev(o[0]), s01 * l00 + s11 * l10, (s11 * l11) * sigmoid_sp_dev(o[2]), 0.f};
+}
+
+// ------------------------------------------------------------------------------------------------
 // Model: canonical pHNN with the cart-pole mass matrix (src/pHNN_canonical.py:172-273,
 // src/mass_matrix.py:270-362, src/coordinate_transforms.py:20-130)
 // ------------------------------------------------------------------------------------------------
-template <int HID_, int MM_ = MM_F32, int MI_ = 1>
+template <int HID_, int MM_ = MM_F32, int MI_ = 1, int MT_ = MASS_CARTPOLE>
 struct CanonModel {
-  static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_, MI = MI_;
+  static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_, MI = MI_, MT = MT_;  // MT: mass matrix type
   static constexpr bool SPLIT = false;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int oH = 0;
   static constexpr int oC = oH + LayH2<HID, MM>::SIZE;  // a, b, c, 0 | Rd[4] | sigmoid(R_diag_raw)[4] | G[4][MI] (16 slots)
   static constexpr int oCG = oC + 12;
-  static constexpr int IMG = oC + 28;
+  static constexpr int oCW = oC + 28;  // MT = constant: M^-1 entries (w00, w01, w11, 0); M itself sits in a, b, c
+  static constexpr int oMn = oC + 32;  // MT = diagonal / full: LayM image of M_net.mlp
+  static constexpr int IMG = oMn + (MT_ >= MASS_DIAGONAL ? LayM::SIZE : 0);
+
+  // M(q) and M^-1(q) for the MassMatrixNetwork types (MT >= 1)
+  DEV static void mass_eval(const float* L, Lane ln, f32x4 y, float (&m)[3], float (&w)[3], MTape& mt) {
+    if (MT == MASS_CONSTANT) {
+      m[0] = L[oC + 0]; m[1] = L[oC + 1]; m[2] = L[oC + 2];
+      w[0] = L[oCW + 0]; w[1] = L[oCW + 1]; w[2] = L[oCW + 2];
+    } else {
+      mnet_fwd(L + oMn, ln, f32x4{y[0], y[1], 0.f, 0.f}, mt);
+      mass_from_outputs<MT>(mt.o, m, w);
+    }
+  }
 
   DEV static float Base_Gu(const float* L, int row, f32x4 u) {  // (G u)_row
     float s = 0.f;
@@ -1129,6 +1227,22 @@ struct CanonModel {
   template <bool WANT_H, bool ST = false>
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 y, f32x4 u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
+    if constexpr (MT != MASS_CARTPOLE) {  // general MassMatrixNetwork: no det fudge, M^-1 as the reference forms it
+      float m[3], w[3];
+      MTape mt;
+      mass_eval(L, ln, y, m, w, mt);
+      f32x4 z = {y[0], y[1], m[0] * y[2] + m[1] * y[3], m[1] * y[2] + m[2] * y[3]};
+      HTape<HID> tp;
+      f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, z, tp, Hval);
+      if (ST) {
+        store_act<T>(stash, ln, tp.a2);
+        store_act<T>(stash + T * 256, ln, tp.q1);
+        if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+      }
+      float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + Base_Gu(L, 2, u);
+      float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + Base_Gu(L, 3, u);
+      return f32x4{w[0] * z[2] + w[1] * z[3], w[1] * z[2] + w[2] * z[3], w[0] * dp0 + w[1] * dp1, w[1] * dp0 + w[2] * dp1};
+    }
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
     float sn, cs;
     sincos_dev(y[1], sn, cs);
@@ -1157,6 +1271,53 @@ struct CanonModel {
   DEV static void vjp(const float* L, float* scr, Lane ln, f32x4 y, f32x4 u, f32x4 lam, f32x4& ybar, f32x4& ubar,
                       const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     keep_lds_reads_local();
+    if constexpr (MT != MASS_CARTPOLE) {
+      static_assert(!WG, "weight-gradient records: cart-pole mass matrix only");
+      float m[3], w[3];
+      MTape mt;
+      mass_eval(L, ln, y, m, w, mt);
+      f32x4 z = {y[0], y[1], m[0] * y[2] + m[1] * y[3], m[1] * y[2] + m[2] * y[3]};
+      HTape<HID> tp;
+      float Hdummy;
+      f32x4 dH;
+      if (ST) {
+        load_act<T>(stash, ln, tp.a2);
+        load_act<T>(stash + T * 256, ln, tp.q1);
+        dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+        hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
+      } else {
+        dH = hnet_grad<HID, false, MM>(L + oH, ln, z, tp, Hdummy);
+      }
+      const float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
+      const float dp0 = (-dH[0] - Rd2 * dH[2]) + Base_Gu(L, 2, u);
+      const float dp1 = (-dH[1] - Rd3 * dH[3]) + Base_Gu(L, 3, u);
+      const float pb0 = lam[0] * w[0] + lam[1] * w[1], pb1 = lam[0] * w[1] + lam[1] * w[2];      // W lam_q
+      const float dpb0 = lam[2] * w[0] + lam[3] * w[1], dpb1 = lam[2] * w[1] + lam[3] * w[2];    // W lam_v
+      f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
+      ubar = Base_Gt(L, dpb0, dpb1);
+      f32x4 zb = hnet_hvp<HID, MM>(L + oH, ln, tp, v);
+      zb[2] += pb0;
+      zb[3] += pb1;
+      ybar = f32x4{zb[0], zb[1], zb[2] * m[0] + zb[3] * m[1], zb[2] * m[1] + zb[3] * m[2]};
+      if (MT >= MASS_DIAGONAL) {  // M(q) carries gradient: p = M qdot and the two uses of M^-1 (d W = -W dM W)
+        const float W4[4] = {w[0], w[1], w[1], w[2]};
+        const float Wb[4] = {lam[0] * z[2] + lam[2] * dp0, lam[0] * z[3] + lam[2] * dp1,
+                             lam[1] * z[2] + lam[3] * dp0, lam[1] * z[3] + lam[3] * dp1};
+        float Tm[4], Um[4], Mb[4];
+        Tm[0] = W4[0] * Wb[0] + W4[1] * Wb[2]; Tm[1] = W4[0] * Wb[1] + W4[1] * Wb[3];
+        Tm[2] = W4[2] * Wb[0] + W4[3] * Wb[2]; Tm[3] = W4[2] * Wb[1] + W4[3] * Wb[3];
+        Um[0] = Tm[0] * W4[0] + Tm[1] * W4[2]; Um[1] = Tm[0] * W4[1] + Tm[1] * W4[3];
+        Um[2] = Tm[2] * W4[0] + Tm[3] * W4[2]; Um[3] = Tm[2] * W4[1] + Tm[3] * W4[3];
+        Mb[0] = zb[2] * y[2] - Um[0];
+        Mb[1] = zb[2] * y[3] - Um[1];
+        Mb[2] = zb[3] * y[2] - Um[2];
+        Mb[3] = zb[3] * y[3] - Um[3];
+        f32x4 qb = mnet_bwd(L + oMn, ln, mt, mass_outputs_bar<MT>(mt.o, Mb));
+        ybar[0] += qb[0];
+        ybar[1] += qb[1];
+      }
+      return;
+    }
     float a = L[oC + 0], b = L[oC + 1], c = L[oC + 2];
     float sn, cs;
     sincos_dev(y[1], sn, cs);
@@ -2246,7 +2407,7 @@ struct BlobOf<PhnnModel<N, HID, FIXG, MM, MI>> {
   static constexpr int SIZE = H.oW1 + H.size + (FIXG ? 0 : G.size);
 };
 template <int HID, int MM, int MI>
-struct BlobOf<CanonModel<HID, MM, MI>> {
+struct BlobOf<CanonModel<HID, MM, MI, MASS_CARTPOLE>> {
   static constexpr int oRd = 0;  // R_diag_raw (4) | G (4 MI) | log_a, b, log_c | H_net
   static constexpr BlobH<4, HID> H{4 + 4 * MI + 3};
   static constexpr int SIZE = H.oW1 + H.size;

@@ -78,6 +78,17 @@ size_t mlp_count(const phnn_mlp_shape& s, int in, int out) {
   return c;
 }
 
+// floats of the mass-matrix block of a CANONICAL blob (include/phnn_mpc.h); 0 = invalid
+size_t mass_block_count(const phnn_desc* d) {
+  switch (d->mass_type) {
+    case PHNN_MASS_CARTPOLE: return 3;
+    case PHNN_MASS_CONSTANT: return 4;
+    case PHNN_MASS_DIAGONAL: return mlp_count(d->m_net, 2, 2);
+    case PHNN_MASS_FULL: return mlp_count(d->m_net, 2, 3);
+    default: return 0;
+  }
+}
+
 size_t weight_count(const phnn_desc* d) {
   if (!d || d->n < 1 || d->n > PHNN_MAX_N || d->m < 1 || d->m > PHNN_MAX_M) return 0;
   int n = d->n, m = d->m;
@@ -90,7 +101,9 @@ size_t weight_count(const phnn_desc* d) {
   if (d->kind == PHNN_MODEL_CANONICAL) {
     size_t h = mlp_count(d->h_net, n, 1);
     if (!h || n != 4) return 0;
-    return (size_t)n + (size_t)n * m + 3 + h;
+    size_t mass = mass_block_count(d);
+    if (!mass) return 0;
+    return (size_t)n + (size_t)n * m + mass + h;
   }
   if (d->kind == PHNN_MODEL_ODEFUNC) return mlp_count(d->h_net, n + m, n);
   return 0;
@@ -171,6 +184,16 @@ int pick_variant(const phnn_desc* d, const phnn_options& opt, std::string* why) 
              "(have n=2|4, fixed or learned G, hidden widths up to 128, H_net 2 hidden layers, R_net/G_net 1)",
              d->n, d->h_net.depth, hid, d->r_net.depth, d->r_net.hidden[0], d->fixed_G);
     *why = buf;
+    return V_NONE;
+  }
+  if (d->kind == PHNN_MODEL_CANONICAL && d->mass_type != PHNN_MASS_CARTPOLE) {
+    // general MassMatrixNetwork (constant / diagonal / full): 128-wide f16x2 kernels, M_net.mlp two hidden layers <= 64
+    const bool mlp_ok = d->mass_type == PHNN_MASS_CONSTANT || same_hidden(d->m_net, 2, 64);
+    if (d->n == 4 && d->m == 1 && same_hidden(d->h_net, 2, 128) && mlp_ok && matmul_mode(opt, 128) == MM_F16X2)
+      return d->mass_type == PHNN_MASS_CONSTANT ? V_CANON_128_H_MCONST
+                                                : (d->mass_type == PHNN_MASS_DIAGONAL ? V_CANON_128_H_MDIAG : V_CANON_128_H_MFULL);
+    *why = "canonical pHNN with a MassMatrixNetwork: kernels exist for m = 1, H_net two hidden layers up to 128, M_net.mlp "
+           "two hidden layers up to 64, f16x2 products";
     return V_NONE;
   }
   if (d->kind == PHNN_MODEL_CANONICAL) {
@@ -444,6 +467,7 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
   else if (d->kind == PHNN_MODEL_CANONICAL) W = mx <= 64 ? 64 : 128;
   else W = (d->n == 2 && mx <= 64) ? 64 : 128;
   if (d->m > 1) W = 128;  // the m = 2 kernels exist at width 128 only
+  if (d->kind == PHNN_MODEL_CANONICAL && d->mass_type != PHNN_MASS_CARTPOLE) W = 128;  // so do the MassMatrixNetwork ones
   if (mx > W || mx < 1) {
     char buf[160];
     snprintf(buf, sizeof buf, "hidden width %d exceeds the widest kernel (%d) for this model family / state dimension", mx, W);
@@ -467,9 +491,18 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
     set_w(pd->h_net);
     if (!d->fixed_G) set_w(pd->g_net);
   } else if (d->kind == PHNN_MODEL_CANONICAL) {
-    size_t head = (size_t)n + (size_t)n * m + 3;
+    const bool mlp_mass = d->mass_type == PHNN_MASS_DIAGONAL || d->mass_type == PHNN_MASS_FULL;
+    size_t head = (size_t)n + (size_t)n * m + (mlp_mass ? 0 : mass_block_count(d));
     pblob->assign(p, p + head);
     p += head;
+    if (mlp_mass) {  // M_net.mlp: q_dim = 2 inputs, padded to the 64-wide image
+      if (max_hidden(d->m_net) > 64 || d->m_net.depth != 2) {
+        *why = "MassMatrixNetwork mlp: two hidden layers of at most 64 units have a kernel";
+        return false;
+      }
+      p = pad_mlp(*pblob, p, d->m_net, 2, d->mass_type == PHNN_MASS_DIAGONAL ? 2 : 3, 64);
+      for (int l = 0; l < pd->m_net.depth; ++l) pd->m_net.hidden[l] = 64;
+    }
     p = pad_mlp(*pblob, p, d->h_net, n, 1, W);
     set_w(pd->h_net);
   } else {
@@ -533,13 +566,44 @@ void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
   img.assign(M::IMG, 0.f);
   const float* Rd = p; p += 4;
   const float* G = p; p += 4 * M::MI;
-  float log_a = p[0], b = p[1], log_c = p[2];
-  p += 3;
-  p = pack_h2<HID, M::MM>(img.data() + M::oH, p, 4);
   float* c = img.data() + M::oC;
-  c[0] = expf(log_a) + 1e-3f;  // src/mass_matrix.py:286-288
-  c[1] = b;
-  c[2] = expf(log_c) + 1e-3f;
+  if (M::MT == MASS_CARTPOLE) {
+    float log_a = p[0], b = p[1], log_c = p[2];
+    p += 3;
+    c[0] = expf(log_a) + 1e-3f;  // src/mass_matrix.py:286-288
+    c[1] = b;
+    c[2] = expf(log_c) + 1e-3f;
+  } else if (M::MT == MASS_CONSTANT) {
+    // L = tril(L_tril) with softplus(diag) + 1e-3; M = L L^T; M^-1 = L^-T L^-1  (src/mass_matrix.py:141-152, 183-194)
+    const float l00 = softplus_host(p[0]) + 1e-3f, l10 = p[2], l11 = softplus_host(p[3]) + 1e-3f;
+    p += 4;
+    c[0] = l00 * l00;
+    c[1] = l00 * l10;
+    c[2] = l10 * l10 + l11 * l11;
+    const float i00 = 1.0f / l00, i11 = 1.0f / l11, i10 = -l10 / (l00 * l11);
+    float* cw = img.data() + M::oCW;
+    cw[0] = i00 * i00 + i10 * i10;
+    cw[1] = i10 * i11;
+    cw[2] = i11 * i11;
+  } else {  // M_net.mlp (already padded to 64): 2 -> 64 -> 64 -> out
+    const int nout = M::MT == MASS_DIAGONAL ? 2 : 3;
+    float* dm = img.data() + M::oMn;
+    const float* W1 = p; p += 64 * 2;
+    const float* b1 = p; p += 64;
+    const float* W2 = p; p += 64 * 64;
+    const float* b2 = p; p += 64;
+    const float* Wo = p; p += (size_t)nout * 64;
+    const float* bo = p; p += nout;
+    pack_in_frag<64>(dm + LayM::oW1f, W1, 2);
+    memcpy(dm + LayM::oB1, b1, sizeof(float) * 64);
+    pack_rows(dm + LayM::oW2, W2, 64, 64, LayM::LD);
+    memcpy(dm + LayM::oB2, b2, sizeof(float) * 64);
+    pack_rows(dm + LayM::oWo, Wo, nout, 64, LayM::LR);
+    memcpy(dm + LayM::oBo, bo, sizeof(float) * nout);
+    pack_in_frag_T<64>(dm + LayM::oWoTf, Wo, nout);
+    pack_cols_as_rows(dm + LayM::oW1T, W1, 64, 2, LayM::LR);
+  }
+  p = pack_h2<HID, M::MM>(img.data() + M::oH, p, 4);
   for (int i = 0; i < 4; ++i) c[4 + i] = softplus_host(Rd[i]) + 1e-4f;  // src/pHNN_canonical.py:162
   // softplus'(raw) = sigmoid(raw) (threshold 20 as torch.nn.functional.softplus): the weight-gradient kernels need it
   for (int i = 0; i < 4; ++i) c[8 + i] = Rd[i] > 20.f ? 1.0f : (float)(1.0 / (1.0 + std::exp(-(double)Rd[i])));
@@ -617,6 +681,9 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_PHNN_4_128_FIX_H_M2: pack_phnn<M_PHNN_4_128_FIX_H_M2>(img, d, blob); break;
     case V_PHNN_4_128_GNET_H_M2: pack_phnn<M_PHNN_4_128_GNET_H_M2>(img, d, blob); break;
     case V_CANON_128_H_M2: pack_canon<M_CANON_128_H_M2>(img, d, blob); break;
+    case V_CANON_128_H_MCONST: pack_canon<M_CANON_128_H_MCONST>(img, d, blob); break;
+    case V_CANON_128_H_MDIAG: pack_canon<M_CANON_128_H_MDIAG>(img, d, blob); break;
+    case V_CANON_128_H_MFULL: pack_canon<M_CANON_128_H_MFULL>(img, d, blob); break;
     default: break;
   }
 }

@@ -186,6 +186,8 @@ class _EngineBacked(nn.Module):
 
     def _check_supported(self):
         for name, mod in self.named_modules():
+            if isinstance(mod, MassMatrixNetwork) and mod.activation_name != "Tanh":
+                raise NotImplementedError(f"{name}: the M_net.mlp kernel implements Tanh, got {mod.activation_name}")
             if isinstance(mod, MLP) and (not mod.plain or mod.activation_name != "Tanh"):
                 raise NotImplementedError(
                     f"{name}: the rollout kernels implement Linear/Tanh MLPs (bias, no LayerNorm/Dropout), the only "
@@ -256,6 +258,64 @@ class CartPoleMassMatrix(nn.Module):
         return {"a": a, "b": b, "c": c}
 
 
+class MassMatrixNetwork(nn.Module):
+    """Parameters of the general learnable mass matrix (src/mass_matrix.py:15-216), same keys as the reference:
+    'constant' -> L_tril (q_dim, q_dim); 'diagonal' / 'full' -> mlp = Sequential(Linear, act, ..., Linear) with q_dim
+    resp. q_dim (q_dim + 1) / 2 outputs.  The hot path evaluates M(q) and M^-1(q) in-kernel (q_dim = 2); forward /
+    inverse below are the small closed forms for the reference's host-side helpers."""
+
+    def __init__(self, q_dim, mass_type="diagonal", hidden_sizes=(64, 64), activation=None, init_scale=1.0):
+        super().__init__()
+        if mass_type not in ("constant", "diagonal", "full"):
+            raise ValueError(f"Unknown mass_type: {mass_type}")
+        self.q_dim, self.mass_type, self.init_scale = q_dim, mass_type, init_scale
+        self.activation_name = type(activation).__name__ if activation is not None else "Tanh"
+        if mass_type == "constant":
+            self.L_tril = nn.Parameter(torch.eye(q_dim) * init_scale)
+            self.mlp = None
+            return
+        out = q_dim if mass_type == "diagonal" else q_dim * (q_dim + 1) // 2
+        mods, prev = [], q_dim
+        for h in hidden_sizes:
+            mods += [nn.Linear(prev, h), activation if activation is not None else nn.Tanh()]
+            prev = h
+        mods.append(nn.Linear(prev, out))
+        self.mlp = nn.Sequential(*mods)
+        nn.init.zeros_(self.mlp[-1].weight)
+        nn.init.zeros_(self.mlp[-1].bias)
+        if mass_type == "full":  # diagonal Cholesky entries start at log(init_scale)
+            with torch.no_grad():
+                idx, k = [], 0
+                for i in range(q_dim):
+                    idx.append(k)
+                    k += i + 2
+                self.mlp[-1].bias[idx] = math.log(init_scale)
+
+    def _chol(self, raw):
+        """(..., n, n) raw lower-triangular entries -> L with softplus(diag) + 1e-3"""
+        n = self.q_dim
+        L = torch.tril(raw)
+        d = torch.nn.functional.softplus(torch.diagonal(L, dim1=-2, dim2=-1)) + 1e-3
+        return L - torch.diag_embed(torch.diagonal(L, dim1=-2, dim2=-1)) + torch.diag_embed(d)
+
+    def forward(self, q):
+        B = q.shape[0]
+        if self.mass_type == "constant":
+            L = self._chol(self.L_tril)
+            return (L @ L.T).unsqueeze(0).expand(B, -1, -1)
+        o = self.mlp(q)
+        if self.mass_type == "diagonal":
+            return torch.diag_embed(torch.exp(o) + 1e-3)
+        raw = torch.zeros(B, self.q_dim, self.q_dim, dtype=o.dtype, device=o.device)
+        r, c = torch.tril_indices(self.q_dim, self.q_dim, offset=0)
+        raw[:, r, c] = o
+        L = self._chol(raw)
+        return torch.bmm(L, L.transpose(1, 2))
+
+    def inverse(self, q):
+        return torch.linalg.inv(self.forward(q))
+
+
 class pHNN_Canonical(_EngineBacked):
     def __init__(self, config_path: str):
         super().__init__()
@@ -265,10 +325,12 @@ class pHNN_Canonical(_EngineBacked):
         self.state_dim, self.input_dim = mc["state_dim"], mc["input_dim"]
         self.q_dim = self.state_dim // 2
         mass = mc.get("mass_matrix", {})
-        if mass.get("type", "cartpole") != "cartpole":
-            raise NotImplementedError("only mass_matrix.type == 'cartpole' (the shipped config) has a kernel; "
-                                      "MassMatrixNetwork variants are out of scope (SURVEY.md 2.1 #4)")
-        self.M_net = CartPoleMassMatrix(mass.get("init_a", 1.0), mass.get("init_b", 0.1), mass.get("init_c", 1.0))
+        mass_type = mass.get("type", "cartpole")
+        if mass_type == "cartpole":  # src/pHNN_canonical.py:67-86
+            self.M_net = CartPoleMassMatrix(mass.get("init_a", 1.0), mass.get("init_b", 0.1), mass.get("init_c", 1.0))
+        else:
+            self.M_net = MassMatrixNetwork(self.q_dim, mass_type, mass.get("hidden_sizes", [64, 64]),
+                                           _activation(mass.get("activation", "nn.Tanh"))(), mass.get("init_scale", 1.0))
         self.H_net = _mlp_from(mc["H_mlp"], self.state_dim, 1)
         J = torch.zeros(self.state_dim, self.state_dim)
         J[:self.q_dim, self.q_dim:] = torch.eye(self.q_dim)

@@ -42,6 +42,27 @@ def _mlp_layers(sd, prefix):
     return layers
 
 
+def _mass_kind(sd):
+    """Which mass matrix a pHNN_Canonical state_dict carries (src/pHNN_canonical.py:67-86) -> (mass_type, mlp layers)."""
+    if "M_net.log_a" in sd:
+        for k in ("M_net.b", "M_net.log_c"):
+            if k not in sd:
+                raise ValueError(f"pHNN_Canonical state_dict: CartPoleMassMatrix parameter {k} is missing")
+        return _capi.MASS_CARTPOLE, None
+    if "M_net.L_tril" in sd:
+        if _np(sd["M_net.L_tril"]).shape != (2, 2):
+            raise ValueError("MassMatrixNetwork: only q_dim = 2 is supported")
+        return _capi.MASS_CONSTANT, None
+    if any(k.startswith("M_net.mlp.") for k in sd):
+        Ml = _mlp_layers(sd, "M_net.mlp.")
+        out, qd = Ml[-1][0].shape[0], Ml[0][0].shape[1]
+        if qd != 2 or out not in (2, 3):
+            raise ValueError("MassMatrixNetwork: only q_dim = 2 (2 diagonal or 3 Cholesky outputs) is supported")
+        return (_capi.MASS_DIAGONAL if out == 2 else _capi.MASS_FULL), Ml
+    raise ValueError("pHNN_Canonical state_dict without mass-matrix parameters (M_net.log_a/b/log_c, M_net.L_tril "
+                     "or M_net.mlp.*)")
+
+
 def _flat(layers):
     out = []
     for W, b in layers:
@@ -111,15 +132,19 @@ def pack_state_dict(sd, kind=None, state_dim=None, input_dim=None, activation="t
         G = _np(sd["G"])
         m = G.shape[1]
         H = _mlp_layers(sd, "H_net.net.")
-        for k in ("M_net.log_a", "M_net.b", "M_net.log_c"):
-            if k not in sd:
-                raise ValueError("pHNN_Canonical state_dict without CartPoleMassMatrix parameters "
-                                 "(M_net.log_a/b/log_c): only mass_matrix.type == 'cartpole' is supported")
         d.n, d.m, d.fixed_G = n, m, 1
         d.h_net = _capi.MlpShape.of([W.shape[0] for W, _ in H[:-1]])
-        parts += [Rd.ravel(), G.ravel(),
-                  np.array([_np(sd["M_net.log_a"]).item(), _np(sd["M_net.b"]).item(), _np(sd["M_net.log_c"]).item()],
-                           np.float32)]
+        parts += [Rd.ravel(), G.ravel()]
+        mass, Ml = _mass_kind(sd)
+        d.mass_type = mass
+        if mass == _capi.MASS_CARTPOLE:  # CartPoleMassMatrix (src/mass_matrix.py:263-268)
+            parts.append(np.array([_np(sd["M_net.log_a"]).item(), _np(sd["M_net.b"]).item(),
+                                   _np(sd["M_net.log_c"]).item()], np.float32))
+        elif mass == _capi.MASS_CONSTANT:  # MassMatrixNetwork 'constant': L_tril (q_dim, q_dim)
+            parts.append(_np(sd["M_net.L_tril"]).ravel())
+        else:  # 'diagonal' / 'full': M_net.mlp
+            d.m_net = _capi.MlpShape.of([W.shape[0] for W, _ in Ml[:-1]])
+            parts += _flat(Ml)
         parts += _flat(H)
     elif kind == _capi.MODEL_ODEFUNC:
         L = _mlp_layers(sd, "network.")
@@ -170,8 +195,14 @@ def blob_layout(sd, kind=None):
     elif kind == _capi.MODEL_CANONICAL:
         add("R_diag_raw", _np(sd["R_diag_raw"]).shape)
         add("G", _np(sd["G"]).shape)
-        for k in ("M_net.log_a", "M_net.b", "M_net.log_c"):
-            add(k, ())
+        mass, _ = _mass_kind(sd)
+        if mass == _capi.MASS_CARTPOLE:
+            for k in ("M_net.log_a", "M_net.b", "M_net.log_c"):
+                add(k, ())
+        elif mass == _capi.MASS_CONSTANT:
+            add("M_net.L_tril", (2, 2))
+        else:
+            add_mlp("M_net.mlp.")
         add_mlp("H_net.net.")
     elif kind == _capi.MODEL_ODEFUNC:
         add_mlp("network.")

@@ -180,3 +180,18 @@ def load_m2_golden():
 
 
 M2_MODELS = ["phnn_m2_fix", "phnn_m2_gnet", "canonical_m2"]
+
+
+def load_named_golden(fname):
+    """golden file with 'w/<model>/<key>' weights -> (arrays, {model name: state_dict})"""
+    with np.load(os.path.join(GOLDEN, fname)) as z:
+        g = {k: z[k] for k in z.files}
+    w = {}
+    for k in list(g):
+        if k.startswith("w/"):
+            _, name, key = k.split("/", 2)
+            w.setdefault(name, {})[key] = g.pop(k)
+    return g, w
+
+
+MASS_TYPES = ["constant", "diagonal", "full"]

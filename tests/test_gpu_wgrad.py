@@ -300,3 +300,51 @@ def test_two_inputs_m2_vs_reference(torch, name):
     assert np.allclose(npy(c), ref["cost"], rtol=1e-5)
     assert np.all(np.abs(npy(gu) - ref["grad_u"]) <= 1e-4 * np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True))
     print(f"{name}: m=2 parity ok, worst parameter-gradient tensor error {worst:.2e}")
+
+
+# ----------------------------------------------------------------------------- MassMatrixNetwork (row f2)
+@pytest.mark.parametrize("name", ol.MASS_TYPES)
+def test_mass_matrix_network_vs_reference(torch, name):
+    """pHNN_Canonical with the general MassMatrixNetwork (constant / diagonal / full, src/mass_matrix.py:15-216):
+    model(y,u), VJP (gradient flows through M(q) and M^-1(q)), Euler / RK4 rollouts with cost and gradients -- against
+    the reference's own outputs (golden_mass.npz) -- and through the drop-in module built from a config."""
+    import tempfile, yaml
+    from phnn_mpc_amd import _capi
+    from phnn_mpc_amd.engine import RolloutEngine
+    from phnn_mpc_amd.models import pHNN_Canonical
+    g, ws = ol.load_named_golden("golden_mass.npz")
+    w = ws[name]
+    eng = RolloutEngine(w)
+    assert f"mass={name}" in eng.variant and not eng.has_wgrad
+    dx, H = eng.forward(g[f"{name}/x"], g[f"{name}/u"])
+    assert np.abs(npy(dx) - g[f"{name}/fwd_dx"]).max() <= 2e-5 * np.abs(g[f"{name}/fwd_dx"]).max()
+    assert np.abs(npy(H) - g[f"{name}/fwd_H"]).max() <= 2e-5 * max(1.0, np.abs(g[f"{name}/fwd_H"]).max())
+    xb, ub = eng.vjp(g[f"{name}/x"], g[f"{name}/u"], g[f"{name}/lam"])
+    assert np.abs(npy(xb) - g[f"{name}/vjp_xbar"]).max() <= 3e-5 * np.abs(g[f"{name}/vjp_xbar"]).max()
+    assert np.abs(npy(ub) - g[f"{name}/vjp_ubar"]).max() <= 3e-5 * np.abs(g[f"{name}/vjp_ubar"]).max()
+    cost = _capi.make_cost(4, 1, [10.0, 200.0, 1.0, 10.0], [0.01], None, -15.0, 15.0)
+    U = g[f"{name}/roll_U"]
+    for integ in ("euler", "rk4"):
+        c, gu, gx = eng.rollout_cost_grad(g[f"{name}/roll_x0"], U, cost, integ, 0.02, want_grad_x0=True)
+        _, traj = eng.rollout_cost(g[f"{name}/roll_x0"], U, cost, integ, 0.02, want_traj=True)
+        assert np.allclose(npy(c), g[f"{name}/roll_{integ}_cost"], rtol=1e-5)
+        assert np.allclose(npy(traj), g[f"{name}/roll_{integ}_traj"], rtol=1e-5, atol=1e-5)
+        rgu = g[f"{name}/roll_{integ}_gu"]
+        gmax = np.abs(rgu).max(axis=(1, 2), keepdims=True)
+        assert np.all(np.abs(npy(gu) - rgu) <= 1e-4 * gmax), (np.abs(npy(gu) - rgu) / gmax).max()
+        rgx = g[f"{name}/roll_{integ}_gx0"]
+        assert np.all(np.abs(npy(gx) - rgx) <= 1e-4 * np.abs(rgx).max(axis=1, keepdims=True))
+        assert np.all(npy(gu)[(U > 15.0) | (U < -15.0)] == 0.0)
+    # the drop-in module from a config with model.mass_matrix.type = <name>
+    cfg = yaml.safe_load(open(CFG))
+    cfg["model"]["mass_matrix"] = {"type": name, "hidden_sizes": [64, 64], "activation": "nn.Tanh", "init_scale": 1.0}
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as tf:
+        yaml.safe_dump(cfg, tf)
+    m = pHNN_Canonical(tf.name)
+    os.unlink(tf.name)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    y, u = torch.tensor(g[f"{name}/x"]), torch.tensor(g[f"{name}/u"])
+    dy, Hm, _ = m(y, u)
+    assert np.abs(npy(dy) - g[f"{name}/fwd_dx"]).max() <= 2e-5 * np.abs(g[f"{name}/fwd_dx"]).max()
+    Mq = m.M_net(y[:, :2])
+    assert Mq.shape == (64, 2, 2) and torch.allclose(torch.bmm(Mq, m.M_net.inverse(y[:, :2])), torch.eye(2).expand(64, 2, 2), atol=1e-5)

@@ -41,9 +41,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header():
-    # phnn_desc: 4 ints + 3 * (1 + 4) ints + activation ; phnn_cost: 64+16+8 floats, 2 floats, int, 16 floats, 2 ints,
+    # phnn_desc: 4 ints + 3 * (1 + 4) ints + activation + mass_type + m_net (1 + 4) ; phnn_cost: 64+16+8 floats, 2 floats, int, 16 floats, 2 ints,
     # float ; phnn_options: 3 ints + 5 reserved ; phnn_plant: 7 doubles
-    assert C.sizeof(_capi.Desc) == 4 * (4 + 3 * 5 + 1)
+    assert C.sizeof(_capi.Desc) == 4 * (4 + 3 * 5 + 1 + 1 + 5)
     assert C.sizeof(_capi.Cost) == 4 * (64 + 16 + 8 + 2 + 1 + 16 + 2 + 1)
     assert C.sizeof(_capi.Options) == 4 * 8
     assert C.sizeof(_capi.Plant) == 8 * 7

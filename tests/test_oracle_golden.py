@@ -232,3 +232,33 @@ def test_oracle_two_inputs_m2(name):
         ref = g[k]
         ours = named[k.split("pt_g.", 1)[1]].reshape(ref.shape)
         assert np.abs(ours - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30), k
+
+
+# ----------------------------------------------------------------------------- MassMatrixNetwork (row f2)
+@pytest.mark.parametrize("name", ol.MASS_TYPES)
+def test_oracle_mass_matrix_network(name):
+    """pHNN_Canonical with MassMatrixNetwork constant / diagonal / full (src/mass_matrix.py:15-216)."""
+    from phnn_mpc_amd import _capi, weights
+    g, ws = ol.load_named_golden("golden_mass.npz")
+    w = ws[name]
+    d, _ = weights.pack_state_dict(w)
+    assert d.mass_type == {"constant": 1, "diagonal": 2, "full": 3}[name]
+    m = ol.OracleModel(w, "f64")
+    dx, H = m.forward(g[f"{name}/x"], g[f"{name}/u"])
+    assert np.allclose(dx, g[f"{name}/fwd_dx"], rtol=1e-9, atol=1e-11) and np.allclose(H, g[f"{name}/fwd_H"], rtol=1e-10, atol=1e-12)
+    xb, ub = m.vjp(g[f"{name}/x"], g[f"{name}/u"], g[f"{name}/lam"])
+    assert np.abs(xb - g[f"{name}/vjp_xbar"]).max() <= 1e-8 * np.abs(g[f"{name}/vjp_xbar"]).max()
+    assert np.abs(ub - g[f"{name}/vjp_ubar"]).max() <= 1e-8 * np.abs(g[f"{name}/vjp_ubar"]).max()
+    cost = _capi.make_cost(4, 1, [10.0, 200.0, 1.0, 10.0], [0.01], None, -15.0, 15.0)
+    for integ in ("euler", "rk4"):
+        r = m.rollout(g[f"{name}/roll_x0"], g[f"{name}/roll_U"], cost, integ, 0.02)
+        assert np.allclose(r["traj"], g[f"{name}/roll_{integ}_traj"], rtol=1e-8, atol=1e-10)
+        assert np.allclose(r["cost"], g[f"{name}/roll_{integ}_cost"], rtol=1e-8)
+        for a, b in ((r["grad_u"], g[f"{name}/roll_{integ}_gu"]), (r["grad_x0"], g[f"{name}/roll_{integ}_gx0"])):
+            assert np.abs(a - b).max() <= 1e-7 * np.abs(b).max()
+    gt = m.wgrad(g[f"{name}/x"], g[f"{name}/u"], g[f"{name}/lam"], g[f"{name}/Hbar"])
+    named = weights.unpack_grad_blob(w, gt)
+    for k in [k for k in g if k.startswith(f"{name}/pt_g.")]:
+        ref = g[k]
+        ours = named[k.split("pt_g.", 1)[1]].reshape(ref.shape)
+        assert np.abs(ours - ref).max() <= 1e-8 * max(np.abs(ref).max(), 1e-30), (k, np.abs(ours - ref).max(), np.abs(ref).max())
