@@ -7,9 +7,9 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/final"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preheat 0 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_fetch.log"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preheat 0 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-other-modes > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preheat 0 --no-cpu-baseline --no-other-modes > /dev/null 2> "$OUT/pmc_fetch.log"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preheat 0 --no-cpu-baseline --no-other-modes > /dev/null 2> "$OUT/pmc_write.log"
 cd "$ROOT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 tools/bench_configs.py > "$OUT/other_configs.jsonl" 2> "$OUT/other_configs.err"
