@@ -354,15 +354,18 @@ def cpu_baseline_torch(w, x0_h, U_h, dt, umax):
     torch.set_num_threads(cores)
     m = TorchPhnn(w, torch.float32)
     args = ([10.0, 200.0, 1.0, 10.0], 0.01, [0.0, 0.0, 0.0, 0.0], -umax, umax, dt)
+    m.rollout_cost_grad(x0_h[:256], U_h[:256], *args)  # warm-up (thread pool, allocator)
     t = time.perf_counter()
-    m.rollout_cost_grad(x0_h[:512], U_h[:512], *args)
-    pilot = 512 / max(time.perf_counter() - t, 1e-6)
-    S = int(min(max(2048, 8.0 * pilot), 8192, x0_h.shape[0]))  # ~8 s of CPU work, bounded (autograd graph memory)
+    m.rollout_cost_grad(x0_h[:1024], U_h[:1024], *args)
+    pilot = 1024 / max(time.perf_counter() - t, 1e-6)
+    S = int(min(8192, x0_h.shape[0]))  # one pass bounded by the autograd graph's memory (~2 GB at 8192 x 50 steps)
+    reps = int(min(max(np.ceil(8.0 * pilot / S), 1), 24))  # ~8 s of CPU work
     t = time.perf_counter()
-    m.rollout_cost_grad(x0_h[:S], U_h[:S], *args)
+    for _ in range(reps):
+        m.rollout_cost_grad(x0_h[:S], U_h[:S], *args)
     el = time.perf_counter() - t
-    return {"value": round(S / el, 1), "unit": "rollouts+grads/s", "cores": cores, "cores_source": src, "cpu_model": model,
-            "kind": "port", "sample": f"first {S} rollouts of the same batch, float32 torch ops + autograd "
+    return {"value": round(reps * S / el, 1), "unit": "rollouts+grads/s", "cores": cores, "cores_source": src, "cpu_model": model,
+            "kind": "port", "sample": f"first {S} rollouts of the same batch x{reps}, float32 torch ops + autograd "
                                       f"(oracle/torch_oracle.py), torch.set_num_threads({cores}), {el:.1f} s"}
 
 
