@@ -2418,26 +2418,32 @@ struct IsPhnn { static constexpr bool value = false; };
 template <int N, int HID, bool FIXG, int MM, int MI>
 struct IsPhnn<PhnnModel<N, HID, FIXG, MM, MI>> { static constexpr bool value = true; };
 
-// one-hidden-layer net (R_net / G_net) part of a record, for the units of this lane.  NOUT used outputs.
+// exchange geometry of k_wgrad_reduce (shared with the host's LDS size): k columns of the B-side array and floats per buffer
+template <class M>
+constexpr int kWgKA = 32 + (IsPhnn<M>::value ? 16 : 0) + (IsPhnn<M>::value && M::Rec::oSmall / M::Rec::VEC == 6 ? 16 : 0);
+template <class M>
+constexpr int kWgXchFloats = M::HID * 36 + M::HID * (kWgKA<M> + 4) + 32 * 20;
+
+// one-hidden-layer net (R_net / G_net) part of a record, for the units of this lane: the vector-shaped sums.  (The
+// output layer's matrix-shaped gradient V2bar = sum obar (x) h goes through the MFMA path with W2bar.)
 template <int N, int HID, int MM, int NOUT>
 struct H1Acc {
   f32x4 c1 = {0, 0, 0, 0};
-  f32x4 V1[4] = {};    // [c] : units on the vector
-  f32x4 V2[NOUT] = {};  // [o]
-  float c2[NOUT] = {};
+  f32x4 V1[4] = {};  // [c] : units on the vector
+  f32x4 V2 = {0, 0, 0, 0};  // MFMA accumulator: rows o = 4q + r, column = this lane's unit 16w + i
+  f32x4 c2 = {0, 0, 0, 0};  // outputs 4q .. 4q+3 of this lane's rollout
 
-  DEV void add(const float* Lh1, int w, Lane ln, f32x4 x, f32x4 hb, const float (&obar)[NOUT]) {
+  // hidden activation of this lane's 4 units (recomputed from x); accumulates c1bar, V1bar, c2bar.  ov = the output
+  // cotangents 4q .. 4q+3 of this lane's rollout (the values that also go to the exchange as A operand rows).
+  DEV f32x4 add(const float* Lh1, int w, Lane ln, f32x4 x, f32x4 hb, f32x4 ov) {
     using Y = LayH1<HID, MM>;
     f32x4 c = *reinterpret_cast<const f32x4*>(Lh1 + Y::oC1 + 16 * w + 4 * ln.q);
     f32x4 h = tanh4_model<HID / 16>(mfma(Lh1[Y::oV1f + w * 64 + ln.lane], sel4(x, ln.q), c));
     c1 += hb;
 #pragma unroll
     for (int k = 0; k < N; ++k) V1[k] += hb * x[k];
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      V2[o] += h * obar[o];
-      c2[o] += obar[o];
-    }
+    c2 += ov;
+    return h;
   }
 
   DEV void write(float* row, const BlobMlp1<N, HID>& B, int w, Lane ln) {
@@ -2451,17 +2457,28 @@ struct H1Acc {
         float t = sum16(V1[k][r]);
         if (ln.i == 0) row[B.oV1 + unit * N + k] = t;
       }
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) {
-        float t = sum16(V2[o][r]);
-        if (ln.i == 0) row[B.oV2 + o * HID + unit] = t;
-      }
+      const int o = 4 * ln.q + r;  // V2bar[o][16w + i]
+      if (o < NOUT) row[B.oV2 + o * HID + 16 * w + ln.i] = V2[r];
     }
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      float t = sum16(c2[o]);
-      if (w == 0 && ln.lane == 0) row[B.oC2 + o] = t;
+    for (int e = 0; e < 4; ++e) {
+      float t = sum16(c2[e]);
+      if (w == 0 && ln.i == 0 && 4 * ln.q + e < NOUT) row[B.oC2 + 4 * ln.q + e] = t;
     }
+  }
+};
+
+// one wave's slice of a record: its unit tile of every big vector + the small vectors of its lane's rollout
+template <int NB>
+struct RecSlice {
+  f32x4 big[NB], sm[10];
+  DEV void load(const float* R, int vec4, int oSmall, int w, Lane ln) {
+    const f32x4* bg = reinterpret_cast<const f32x4*>(R) + w * 64 + ln.lane;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) big[k] = bg[k * vec4];
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(R + oSmall + ln.i * kRecSmall);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sm[k] = s4[k];
   }
 };
 
@@ -2473,6 +2490,7 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   using Rec = typename M::Rec;
   using BL = BlobOf<M>;
   constexpr bool PHNN = IsPhnn<M>::value;
+  constexpr bool GNET = PHNN && Rec::oSmall / Rec::VEC == 6;
   // the hidden x hidden image (the first W2F floats of every model image) is not needed here: stage the rest
   constexpr int SKIP = Y::W2F, KEEP = M::IMG - SKIP;
   static_assert(M::oH == 0 && Y::oW2 == 0, "the W2 image leads the model image");
@@ -2489,11 +2507,15 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   ln.q = ln.lane >> 4;
   ln.w = 0;
   ln.xch = nullptr;
-  // exchange buffers: two arrays (A side: gdot2* | g2, B side: a1 | adot1) of [HID units][32 k] f32, k stored at
-  // position (k & 3) * 8 + (k >> 2) so that lane (i,q) finds the operands of its 8 k-steps contiguously; x2 (ping-pong)
-  constexpr int XLD = 36;  // floats per unit row (32 + pad)
+  // Exchange buffers (x2, ping-pong), all f32, the k index = rollout (16 per segment), stored so that lane (i,q) finds
+  // the operands of its k-steps contiguously:
+  //   XG [HID units][32 k]      gdot2* | g2            A operand of W2bar (rows of this wave)
+  //   XA [HID units][32+16+16]  a1 | adot1 | hR | hG   B operands (W2bar: 32 k; V2bar of R_net / G_net: 16 k each)
+  //   XO [32 rows][16 k]        rbar (rows 0..15) | gbar (rows 16..31)   A operands of the V2bars
+  // 32-k segment: k at position (k & 3) * 8 + (k >> 2); 16-k segments: (k & 3) * 4 + (k >> 2).
+  constexpr int KA = kWgKA<M>, LDG = 36, LDA = KA + 4, LDO = 20;
+  constexpr int XSZ = kWgXchFloats<M>;
   float* X = lds + KEEP;
-  constexpr int XSZ = HID * XLD;
   __syncthreads();
   const float S = 2.8853900817779268f / L[Y::oB3 + 1], k1inv = L[Y::oB3 + 2], Sb = L[Y::oB3 + 3];
   const float c_ad2 = k1inv / S, c_q1 = 1.0f / (S * Sb), c_qd = -2.0f * k1inv / (S * Sb);
@@ -2505,18 +2527,23 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
 #pragma unroll
   for (int t = 0; t < T; ++t) accW2[t] = splat4(0.f);
   f32x4 aW3 = splat4(0.f), aB2 = splat4(0.f), aB1 = splat4(0.f), aW1[4] = {};
-  float aB3 = 0.f, aJ[N * N] = {}, aRd[2] = {};
+  float aB3 = 0.f, aJ[N] = {}, aRd[2] = {};
   H1Acc<N, HID, MM, PHNN ? N * N : 1> accR;
   H1Acc<N, HID, MM, N * M::MI> accG;
 
+  // Records are streamed once and every iteration ends in a workgroup barrier: the next record's slice of this wave
+  // (NBIG + 10 float4) is loaded before the current one is processed, so that its HBM round trip overlaps the work.
+  constexpr int NB = Rec::oSmall / Rec::VEC;
+  RecSlice<NB> nxt;
+  if ((long long)blockIdx.x < p.n_rec) nxt.load(p.rec + (long long)blockIdx.x * Rec::SIZE, Rec::VEC / 4, Rec::oSmall, w, ln);
   int buf = 0;
   for (long long r = blockIdx.x; r < p.n_rec; r += gridDim.x, buf ^= 1) {
-    const float* R = p.rec + r * (long long)Rec::SIZE;
-    const f32x4* big = reinterpret_cast<const f32x4*>(R) + w * 64 + ln.lane;
-    const f32x4 a2 = big[0], q1r = big[Rec::VEC / 4], ad2r = big[2 * (Rec::VEC / 4)], qdr = big[3 * (Rec::VEC / 4)];
-    const f32x4* sm = reinterpret_cast<const f32x4*>(R + Rec::oSmall + ln.i * kRecSmall);
-    const f32x4 x = sm[0], v = sm[1], lam = sm[2], dH = sm[3], uu = sm[8];
-    const float Hbar = sm[9][0];
+    const RecSlice<NB> cur = nxt;
+    if (r + (long long)gridDim.x < p.n_rec)
+      nxt.load(p.rec + (r + (long long)gridDim.x) * Rec::SIZE, Rec::VEC / 4, Rec::oSmall, w, ln);
+    const f32x4 a2 = cur.big[0], q1r = cur.big[1], ad2r = cur.big[2], qdr = cur.big[3];
+    const f32x4 x = cur.sm[0], v = cur.sm[1], lam = cur.sm[2], dH = cur.sm[3], uu = cur.sm[8];
+    const float Hbar = cur.sm[9][0];
     // H_net factors of this lane's 4 units
     const f32x4 a1 = tanh4_model<T>(mfma(w1f, sel4(x, ln.q), b1v));
     const f32x4 d1 = dtanh(a1), d2 = dtanh(a2);
@@ -2532,57 +2559,65 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     aB1 += gd1;
 #pragma unroll
     for (int k = 0; k < N; ++k) aW1[k] += gd1 * x[k] + g1 * v[k];
-    if (w == 0 && ln.q == 0) {
+    float* XG = X + buf * XSZ;
+    float* XA = XG + HID * LDG;
+    float* XO = XA + HID * LDA;
+    const int p16 = (ln.i & 3) * 4 + (ln.i >> 2);  // position of k = rollout i in a 16-k segment
+    f32x4 hR = splat4(0.f), hG = splat4(0.f);
+    if (w == 0) {
       aB3 += Hbar;
-      if (PHNN) {
+      if (PHNN) {  // lane (i,q) keeps row q of Jbar
+        const float lq = sel4(lam, ln.q), hq = sel4(dH, ln.q);
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-#pragma unroll
-          for (int j = 0; j < N; ++j) aJ[i * N + j] += lam[i] * dH[j] - lam[j] * dH[i];
+        for (int j = 0; j < N; ++j) aJ[j] += lq * dH[j] - lam[j] * hq;
       } else {
-        const f32x4 rd = sm[4];
-        aRd[0] += rd[2];
-        aRd[1] += rd[3];
+        aRd[0] += cur.sm[4][2];
+        aRd[1] += cur.sm[4][3];
       }
     }
     if constexpr (PHNN) {
-      float rbar[N * N];
+      // output cotangents 4q .. 4q+3 of this lane's rollout: rbar = small vectors 4.., gbar[i][k] = lam[i] u[k]
+      f32x4 rv = splat4(0.f), gv = splat4(0.f);
 #pragma unroll
-      for (int k = 0; k < (N * N + 3) / 4; ++k) {
-        const f32x4 t = sm[4 + k];
+      for (int k = 0; k < (N * N + 3) / 4; ++k) rv = (ln.q == k) ? cur.sm[4 + k] : rv;
+      hR = accR.add(L + M::oR, w, ln, x, cur.big[4], rv);
+      if (w == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) XO[(4 * ln.q + e) * LDO + p16] = rv[e];
+      }
+      if constexpr (GNET) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (4 * k + e < N * N) rbar[4 * k + e] = t[e];
-      }
-      accR.add(L + M::oR, w, ln, x, big[4 * (Rec::VEC / 4)], rbar);
-      if constexpr (!M::FIXG) {
-        float gbar[N * M::MI];
 #pragma unroll
-        for (int i = 0; i < N; ++i)
+          for (int i = 0; i < N; ++i)
 #pragma unroll
-          for (int k = 0; k < M::MI; ++k) gbar[i * M::MI + k] = lam[i] * uu[k];
-        accG.add(L + M::oGn, w, ln, x, big[5 * (Rec::VEC / 4)], gbar);
+            for (int k = 0; k < M::MI; ++k) gv[e] = (4 * ln.q + e == i * M::MI + k) ? lam[i] * uu[k] : gv[e];
+        hG = accG.add(L + M::oGn, w, ln, x, cur.big[5], gv);
+        if (w == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) XO[(16 + 4 * ln.q + e) * LDO + p16] = gv[e];
+        }
       }
     }
-    // transpose the W2bar factors through LDS: [unit][pos(k)], k = rollout (term 1) / 16 + rollout (term 2)
-    float* XG = X + buf * 2 * XSZ;
-    float* XA = XG + XSZ;
-    const int p1 = (ln.i & 3) * 8 + (ln.i >> 2), p2 = p1 + 4;  // pos(i), pos(16 + i)
+    // transpose the factors through LDS: [unit][position of k], k = rollout
+    const int p1 = (ln.i & 3) * 8 + (ln.i >> 2), p2 = p1 + 4;  // positions of k = i and k = 16 + i in the 32-k segment
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int unit = 16 * w + 4 * ln.q + rr;
-      XG[unit * XLD + p1] = gd2[rr];
-      XG[unit * XLD + p2] = g2[rr];
-      XA[unit * XLD + p1] = a1[rr];
-      XA[unit * XLD + p2] = ad1[rr];
+      XG[unit * LDG + p1] = gd2[rr];
+      XG[unit * LDG + p2] = g2[rr];
+      XA[unit * LDA + p1] = a1[rr];
+      XA[unit * LDA + p2] = ad1[rr];
+      if (PHNN) XA[unit * LDA + 32 + p16] = hR[rr];
+      if (GNET) XA[unit * LDA + 48 + p16] = hG[rr];
     }
     __syncthreads();
     // rows 16w.. of W2bar: A = XG[16w + i][k], B = XA[16nt + i][k], k-step s <-> k = 4s + q <-> position 8q + s
-    const f32x4* ga = reinterpret_cast<const f32x4*>(XG + (16 * w + ln.i) * XLD + 8 * ln.q);
+    const f32x4* ga = reinterpret_cast<const f32x4*>(XG + (16 * w + ln.i) * LDG + 8 * ln.q);
     const f32x4 g0 = ga[0], g1v = ga[1];
 #pragma unroll
     for (int nt = 0; nt < T; ++nt) {
-      const f32x4* ba = reinterpret_cast<const f32x4*>(XA + (16 * nt + ln.i) * XLD + 8 * ln.q);
+      const f32x4* ba = reinterpret_cast<const f32x4*>(XA + (16 * nt + ln.i) * LDA + 8 * ln.q);
       const f32x4 b0 = ba[0], b1 = ba[1];
       f32x4 acc = accW2[nt];
 #pragma unroll
@@ -2590,6 +2625,18 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) acc = mfma(g1v[s2], b1[s2], acc);
       accW2[nt] = acc;
+    }
+    if constexpr (PHNN) {  // V2bar[o][16w + i] += sum_k obar[o][k] h[16w + i][k]   (k-step s <-> k = 4s + q <-> position 4q + s)
+      const f32x4 oa = *reinterpret_cast<const f32x4*>(XO + ln.i * LDO + 4 * ln.q);
+      const f32x4 hb4 = *reinterpret_cast<const f32x4*>(XA + (16 * w + ln.i) * LDA + 32 + 4 * ln.q);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) accR.V2 = mfma(oa[s2], hb4[s2], accR.V2);
+      if constexpr (GNET) {
+        const f32x4 og = *reinterpret_cast<const f32x4*>(XO + (16 + ln.i) * LDO + 4 * ln.q);
+        const f32x4 hg4 = *reinterpret_cast<const f32x4*>(XA + (16 * w + ln.i) * LDA + 48 + 4 * ln.q);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) accG.V2 = mfma(og[s2], hg4[s2], accG.V2);
+      }
     }
   }
   // ---- write this workgroup's partial gradient (every entry of its row that carries a gradient)
@@ -2620,14 +2667,14 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   }
   if constexpr (PHNN) {
 #pragma unroll
-    for (int k = 0; k < N * N; ++k) {
-      float t = sum16(aJ[k]);
-      if (w == 0 && ln.lane == 0) row[BL::oJ + k] = t;
+    for (int j = 0; j < N; ++j) {
+      float t = sum16(aJ[j]);
+      if (w == 0 && ln.i == 0 && ln.q < N) row[BL::oJ + ln.q * N + j] = t;
     }
     accR.write(row, BL::R, w, ln);
     if constexpr (!M::FIXG) accG.write(row, BL::G, w, ln);
   } else {
-    // R_diag_raw: only rows 2, 3 reach the output; softplus' = sigmoid(raw) (image constants oC[12..15])
+    // R_diag_raw: only rows 2, 3 reach the output; softplus' = sigmoid(raw) (image constants oC[8..11])
     float t2 = sum16(aRd[0]), t3 = sum16(aRd[1]);
     if (w == 0 && ln.lane == 0) {
       row[BL::oRd + 0] = 0.f;  // rows 0, 1 of R multiply the dq rows the reference discards: zero gradient

@@ -18,7 +18,7 @@ static WgradSet wgrad_set() {
   g.blob_floats = BlobOf<M>::SIZE;
   g.reduce_waves = M::T;
   using Y = LayH2<M::HID, M::MM>;
-  g.reduce_lds_bytes = (int)sizeof(float) * ((M::IMG - Y::W2F) + 4 * M::HID * 36);
+  g.reduce_lds_bytes = (int)sizeof(float) * ((M::IMG - Y::W2F) + 2 * kWgXchFloats<M>);
   return g;
 }
 
