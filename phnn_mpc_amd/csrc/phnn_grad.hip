@@ -10,7 +10,8 @@ static GradSet grad_set() {
   GradSet g;
   g.grad[0] = k_rollout_grad<M, PHNN_INTEG_EULER, false>;
   g.grad[1] = k_rollout_grad<M, PHNN_INTEG_RK4, false>;
-  g.grad_stash = k_rollout_grad<M, PHNN_INTEG_EULER, true>;
+  g.grad_stash[0] = k_rollout_grad<M, PHNN_INTEG_EULER, true>;
+  g.grad_stash[1] = k_rollout_grad<M, PHNN_INTEG_RK4, true>;
   g.mvjp = k_model_vjp<M>;
   return g;
 }

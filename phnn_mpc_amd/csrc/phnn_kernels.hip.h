@@ -2115,6 +2115,21 @@ DEV float control_cost(const phnn_cost& c, f32x4 u) {
   return cost;
 }
 
+// K1 -> K2 stash of one rollout step of one 16-rollout tile.  Euler: the tape of the one dynamics evaluation
+// (M::STASH floats).  RK4: four stage slots, each the tape of that stage's evaluation followed by the stage state
+// (16 rollouts x float4), so that K2 runs four tape-reading VJPs and no forward evaluation at all.
+template <class M, int INTEG>
+struct StashStep {
+  static constexpr int SLOT = M::STASH + 64;
+  static constexpr int FLOATS = INTEG == PHNN_INTEG_EULER ? M::STASH : 4 * SLOT;
+};
+DEV void store_stage(float* dst, Lane ln, f32x4 y) {  // ln.w: wave within a split tile (0 for whole-tile models)
+  if (ln.q == 0 && ln.w == 0) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(dst) + ln.i);
+}
+DEV f32x4 load_stage(const float* src, Lane ln) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + ln.i);
+}
+
 // K1: forward march.  One wave = 16 rollouts; grid x = ceil(B/16/waves).
 template <class M, int INTEG, bool STASH>
 __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
@@ -2147,16 +2162,25 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
     f32x4 u = clamp_u4<MI>(p.c, load_u<MI>(up, t));
     if (MI == 1) cost = __builtin_fmaf(u[0] * p.c.R[0], u[0], cost);
     else cost += control_cost<MI>(p.c, u);
-    f32x4 k1 = M::template f<false, STASH>(L, scr, ln, x, u, Hd,
-                                           STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr);
+    float* sl = STASH ? p.stash + (tile * p.H + t) * (long long)StashStep<M, INTEG>::FLOATS : nullptr;
+    f32x4 k1 = M::template f<false, STASH>(L, scr, ln, x, u, Hd, sl);
     if (p.dx_out && writer) store_state<N>(p.dx_out + (b * p.H + t) * N, k1);
     if (INTEG == PHNN_INTEG_EULER) {
       x = x + p.dt * k1;
     } else {
-      f32x4 k2 = M::template f<false>(L, scr, ln, x + p.half_dt * k1, u, Hd);
-      f32x4 k3 = M::template f<false>(L, scr, ln, x + p.half_dt * k2, u, Hd);
-      f32x4 k4 = M::template f<false>(L, scr, ln, x + p.dt * k3, u, Hd);
-      x = x + p.sixth_dt * (((k1 + 2.0f * k2) + 2.0f * k3) + k4);
+      // stages 2..4 as a rolled loop (one copy of f in the instruction stream; nothing of one stage is hoisted into
+      // another).  x + dt/6 (((k1 + 2 k2) + 2 k3) + k4), the association of src/integrators.py:97-109.
+      constexpr int SLOT = StashStep<M, INTEG>::SLOT;  // one stage: the tape of f at the stage state + the stage state
+      f32x4 acc = k1, kp = k1;
+#pragma unroll 1
+      for (int s = 1; s < 4; ++s) {
+        const f32x4 y = x + (s == 3 ? p.dt : p.half_dt) * kp;
+        float* ss = STASH ? sl + s * SLOT : nullptr;
+        if (STASH) store_stage(ss + M::STASH, ln, y);
+        kp = M::template f<false, STASH>(L, scr, ln, y, u, Hd, ss);
+        acc = acc + (s == 3 ? 1.0f : 2.0f) * kp;
+      }
+      x = x + p.sixth_dt * acc;
     }
     cost += state_cost<N>(p.c, x);
     if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1) + t + 1) * N, x);
@@ -2201,14 +2225,14 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   float Hd;
   for (int t = p.H - 1; t >= 0; --t) {
     f32x4 x = load_state<N>(tr + (long long)t * N);
-    const f32x4 uraw = load_u<MI>(up, t);
-    const f32x4 u = p.no_cost ? uraw : clamp_u4<MI>(p.c, uraw);
+    f32x4 uraw = load_u<MI>(up, t);
+    f32x4 u = p.no_cost ? uraw : clamp_u4<MI>(p.c, uraw);
     f32x4 dxb = splat4(0.f);
-    if (db) dxb = load_state<N>(db + (long long)t * N) * live;
+    if (INTEG == PHNN_INTEG_EULER && db) dxb = load_state<N>(db + (long long)t * N) * live;
     f32x4 xb, ub, utot;
     float* rec = nullptr;
     if constexpr (WG) rec = p.wrec + ((tile * p.H + t) * STAGES) * (long long)M::Rec::SIZE;
-    if (INTEG == PHNN_INTEG_EULER) {
+    if constexpr (INTEG == PHNN_INTEG_EULER) {
       if constexpr (WG) {
         M::template vjp<STASH, true>(L, scr, ln, x, u, p.dt * lam + dxb, xb, ub,
                                      STASH ? p.stash + (tile * p.H + t) * (long long)M::STASH : nullptr, rec);
@@ -2219,35 +2243,48 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
       lam = lam + xb;
       utot = ub;
     } else {
-      f32x4 k1 = M::template f<false>(L, scr, ln, x, u, Hd);
-      f32x4 y2 = x + p.half_dt * k1;
-      f32x4 k2 = M::template f<false>(L, scr, ln, y2, u, Hd);
-      f32x4 y3 = x + p.half_dt * k2;
-      f32x4 k3 = M::template f<false>(L, scr, ln, y3, u, Hd);
-      f32x4 y4 = x + p.dt * k3;
-      f32x4 yb4, yb3, yb2, yb1;
-      if constexpr (WG) {
-        M::template vjp<false, true>(L, scr, ln, y4, u, p.sixth_dt * lam, yb4, ub, nullptr, rec + 3 * M::Rec::SIZE);
-        utot = ub;
-        M::template vjp<false, true>(L, scr, ln, y3, u, (2.0f * p.sixth_dt) * lam + p.dt * yb4, yb3, ub, nullptr,
-                                     rec + 2 * M::Rec::SIZE);
-        utot += ub;
-        M::template vjp<false, true>(L, scr, ln, y2, u, (2.0f * p.sixth_dt) * lam + p.half_dt * yb3, yb2, ub, nullptr,
-                                     rec + 1 * M::Rec::SIZE);
-        utot += ub;
-        M::template vjp<false, true>(L, scr, ln, x, u, p.sixth_dt * lam + p.half_dt * yb2 + dxb, yb1, ub, nullptr, rec);
-        utot += ub;
-      } else {
-        M::vjp(L, scr, ln, y4, u, p.sixth_dt * lam, yb4, ub);
-        utot = ub;
-        M::vjp(L, scr, ln, y3, u, (2.0f * p.sixth_dt) * lam + p.dt * yb4, yb3, ub);
-        utot += ub;
-        M::vjp(L, scr, ln, y2, u, (2.0f * p.sixth_dt) * lam + p.half_dt * yb3, yb2, ub);
-        utot += ub;
-        M::vjp(L, scr, ln, x, u, p.sixth_dt * lam + p.half_dt * yb2 + dxb, yb1, ub);
-        utot += ub;
+      // RK4, stages as rolled loops (one copy of f / vjp in the instruction stream, no cross-stage hoisting of tape
+      // loads: that is what made the unrolled form spill).  STASH: the stage states and tapes come from K1's stash.
+      constexpr int SLOT = StashStep<M, INTEG>::SLOT;
+      const float* sl = STASH ? p.stash + (tile * p.H + t) * (long long)StashStep<M, INTEG>::FLOATS : nullptr;
+      f32x4 y2 = x, y3 = x, y4 = x;
+      if constexpr (!STASH) {
+        f32x4 y = x;
+#pragma unroll 1
+        for (int s = 0; s < 3; ++s) {
+          const f32x4 k = M::template f<false>(L, scr, ln, y, u, Hd);
+          y = x + (s == 2 ? p.dt : p.half_dt) * k;
+          y2 = s == 0 ? y : y2;
+          y3 = s == 1 ? y : y3;
+          y4 = s == 2 ? y : y4;
+        }
       }
-      lam = lam + yb1 + yb2 + yb3 + yb4;
+      // Registers are full inside vjp: what rides through the four calls is kept to lam, the running sums and (in
+      // recompute mode) the stage states; the step's state, controls and dX cotangent are re-read where a stage
+      // needs them (L2 hits; vjp opens with a compiler memory barrier, so the loads stay where they are written).
+      f32x4 ysum = splat4(0.f), ybn = ysum;
+      utot = splat4(0.f);
+#pragma unroll 1
+      for (int s = 3; s >= 0; --s) {
+        f32x4 y;
+        if constexpr (STASH) y = s == 0 ? load_state<N>(tr + (long long)t * N) : load_stage(sl + s * SLOT + M::STASH, ln);
+        else y = s == 0 ? load_state<N>(tr + (long long)t * N) : (s == 1 ? y2 : (s == 2 ? y3 : y4));
+        const f32x4 us = p.no_cost ? load_u<MI>(up, t) : clamp_u4<MI>(p.c, load_u<MI>(up, t));
+        // cotangent on k_s: dt/6 (1,2,2,1) lam + the next stage's state cotangent times its step factor
+        f32x4 in = ((s == 0 || s == 3) ? p.sixth_dt : 2.0f * p.sixth_dt) * lam;
+        if (s != 3) in = in + (s == 2 ? p.dt : p.half_dt) * ybn;
+        if (s == 0 && db) in = in + load_state<N>(db + (long long)t * N) * live;
+        f32x4 yb;
+        if constexpr (WG) M::template vjp<false, true>(L, scr, ln, y, us, in, yb, ub, nullptr, rec + s * M::Rec::SIZE);
+        else M::template vjp<STASH>(L, scr, ln, y, us, in, yb, ub, STASH ? sl + s * SLOT : nullptr);
+        utot = s == 3 ? ub : utot + ub;
+        ybn = yb;
+        ysum = s == 3 ? yb : ysum + yb;  // ((yb4 + yb3) + yb2) + yb1
+      }
+      lam = lam + ysum;
+      x = load_state<N>(tr + (long long)t * N);
+      uraw = load_u<MI>(up, t);
+      u = p.no_cost ? uraw : clamp_u4<MI>(p.c, uraw);
     }
     lam = lam + cb * state_cost_grad<N>(p.c, x);
     if (tb) lam = lam + load_state<N>(tb + (long long)t * N) * (WG ? live : 1.0f);

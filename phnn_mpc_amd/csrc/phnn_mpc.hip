@@ -21,9 +21,9 @@ thread_local std::string g_create_error;
 struct KernelSet {
   void (*fwd[2])(RollParams);
   void (*grad[2])(RollParams);
-  void (*fwd_stash)(RollParams);   // Euler, K1 keeps the tape for K2
-  void (*grad_stash)(RollParams);  // Euler, K2 reads the tape instead of recomputing it
-  int stash_floats;                // per wave (16 rollouts) per step
+  void (*fwd_stash[2])(RollParams);   // Euler, RK4: K1 keeps the tape(s) for K2
+  void (*grad_stash[2])(RollParams);  // K2 reads the tape(s) instead of recomputing them
+  int stash_floats[2];                // per wave (16 rollouts) per step
   int scr_floats;                  // per-wave LDS scratch
   void (*mfwd)(PointParams);
   void (*mvjp)(PointParams);
@@ -36,8 +36,10 @@ KernelSet make_set(const char* name) {
   KernelSet k;
   k.fwd[0] = k_rollout_fwd<M, PHNN_INTEG_EULER, false>;
   k.fwd[1] = k_rollout_fwd<M, PHNN_INTEG_RK4, false>;
-  k.fwd_stash = k_rollout_fwd<M, PHNN_INTEG_EULER, true>;
-  k.stash_floats = M::STASH;
+  k.fwd_stash[0] = k_rollout_fwd<M, PHNN_INTEG_EULER, true>;
+  k.fwd_stash[1] = k_rollout_fwd<M, PHNN_INTEG_RK4, true>;
+  k.stash_floats[0] = StashStep<M, PHNN_INTEG_EULER>::FLOATS;
+  k.stash_floats[1] = StashStep<M, PHNN_INTEG_RK4>::FLOATS;
   k.scr_floats = M::SCR;
   k.mfwd = k_model_forward<M>;
   k.img_floats = M::IMG;
@@ -57,7 +59,8 @@ bool kernel_set(int v, KernelSet* k) {
   }
   k->grad[0] = g.grad[0];
   k->grad[1] = g.grad[1];
-  k->grad_stash = g.grad_stash;
+  k->grad_stash[0] = g.grad_stash[0];
+  k->grad_stash[1] = g.grad_stash[1];
   k->mvjp = g.mvjp;
   return true;
 }
@@ -878,10 +881,12 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   }
   e = allow_big_lds(h->ks.fwd[0]);
   if (e == hipSuccess) e = allow_big_lds(h->ks.fwd[1]);
-  if (e == hipSuccess) e = allow_big_lds(h->ks.fwd_stash);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.fwd_stash[0]);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.fwd_stash[1]);
   if (e == hipSuccess) e = allow_big_lds(h->ks.grad[0]);
   if (e == hipSuccess) e = allow_big_lds(h->ks.grad[1]);
-  if (e == hipSuccess) e = allow_big_lds(h->ks.grad_stash);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.grad_stash[0]);
+  if (e == hipSuccess) e = allow_big_lds(h->ks.grad_stash[1]);
   if (e == hipSuccess) e = allow_big_lds(h->ks.mfwd);
   if (e == hipSuccess) e = allow_big_lds(h->ks.mvjp);
   if (h->has_wgrad) {
@@ -893,10 +898,12 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   if (h->has_split) {
     if (e == hipSuccess) e = allow_big_lds(h->sp.fwd[0]);
     if (e == hipSuccess) e = allow_big_lds(h->sp.fwd[1]);
-    if (e == hipSuccess) e = allow_big_lds(h->sp.fwd_stash);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.fwd_stash[0]);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.fwd_stash[1]);
     if (e == hipSuccess) e = allow_big_lds(h->sp.grad[0]);
     if (e == hipSuccess) e = allow_big_lds(h->sp.grad[1]);
-    if (e == hipSuccess) e = allow_big_lds(h->sp.grad_stash);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.grad_stash[0]);
+    if (e == hipSuccess) e = allow_big_lds(h->sp.grad_stash[1]);
     if ((size_t)h->sp.lds_floats * sizeof(float) > 160 * 1024) h->has_split = false;
   }
   if (e != hipSuccess) {
@@ -1002,9 +1009,9 @@ static int fill_roll(phnn_handle* h, RollParams* p, const float* x0, const float
 }
 
 size_t phnn_workspace_bytes(const phnn_handle* h, int64_t B, int32_t H, int32_t integrator) {
-  if (!h || B <= 0 || H < 1 || integrator != PHNN_INTEG_EULER) return 0;
+  if (!h || B <= 0 || H < 1 || (integrator != PHNN_INTEG_EULER && integrator != PHNN_INTEG_RK4)) return 0;
   size_t tiles = (size_t)((B + kTileB - 1) / kTileB);
-  return tiles * (size_t)H * (size_t)h->ks.stash_floats * sizeof(float);
+  return tiles * (size_t)H * (size_t)h->ks.stash_floats[integrator] * sizeof(float);
 }
 
 int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
@@ -1018,12 +1025,12 @@ int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   PHNN_ON_DEVICE(h);
   p.cost = cost_dev;
   p.traj = traj_dev;
-  const bool stash = workspace_dev && integrator == PHNN_INTEG_EULER;
-  p.stash = stash ? (float*)workspace_dev : nullptr;
   const long long tiles = (B + kTileB - 1) / kTileB;
-  if (use_split(h, tiles))
-    return launch_split(h, stash ? h->sp.fwd_stash : h->sp.fwd[integrator], p, tiles, (hipStream_t)stream);
-  return launch(h, stash ? h->ks.fwd_stash : h->ks.fwd[integrator], p, tiles, false, (hipStream_t)stream);
+  const bool split = use_split(h, tiles);
+  const bool stash = workspace_dev != nullptr;
+  p.stash = (float*)workspace_dev;
+  if (split) return launch_split(h, stash ? h->sp.fwd_stash[integrator] : h->sp.fwd[integrator], p, tiles, (hipStream_t)stream);
+  return launch(h, stash ? h->ks.fwd_stash[integrator] : h->ks.fwd[integrator], p, tiles, false, (hipStream_t)stream);
 }
 
 int phnn_rollout_grad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
@@ -1048,12 +1055,12 @@ int phnn_rollout_vjp(phnn_handle* h, const float* x0_dev, const float* u_dev, in
   p.cost_bar = cost_bar_dev;
   p.grad_u = grad_u_dev;
   p.grad_x0 = grad_x0_dev;
-  const bool stash = workspace_dev && integrator == PHNN_INTEG_EULER;
-  p.stash = stash ? (float*)workspace_dev : nullptr;
   const long long tiles = (B + kTileB - 1) / kTileB;
-  if (use_split(h, tiles))
-    return launch_split(h, stash ? h->sp.grad_stash : h->sp.grad[integrator], p, tiles, (hipStream_t)stream);
-  return launch(h, stash ? h->ks.grad_stash : h->ks.grad[integrator], p, tiles, false, (hipStream_t)stream);
+  const bool split = use_split(h, tiles);
+  const bool stash = workspace_dev != nullptr;
+  p.stash = (float*)workspace_dev;
+  if (split) return launch_split(h, stash ? h->sp.grad_stash[integrator] : h->sp.grad[integrator], p, tiles, (hipStream_t)stream);
+  return launch(h, stash ? h->ks.grad_stash[integrator] : h->ks.grad[integrator], p, tiles, false, (hipStream_t)stream);
 }
 
 // ---- training side --------------------------------------------------------------------------

@@ -9,10 +9,12 @@ static SplitSet split_set() {
   SplitSet g;
   g.fwd[0] = k_rollout_fwd<M, PHNN_INTEG_EULER, false>;
   g.fwd[1] = k_rollout_fwd<M, PHNN_INTEG_RK4, false>;
-  g.fwd_stash = k_rollout_fwd<M, PHNN_INTEG_EULER, true>;
+  g.fwd_stash[0] = k_rollout_fwd<M, PHNN_INTEG_EULER, true>;
+  g.fwd_stash[1] = k_rollout_fwd<M, PHNN_INTEG_RK4, true>;
   g.grad[0] = k_rollout_grad<M, PHNN_INTEG_EULER, false>;
   g.grad[1] = k_rollout_grad<M, PHNN_INTEG_RK4, false>;
-  g.grad_stash = k_rollout_grad<M, PHNN_INTEG_EULER, true>;
+  g.grad_stash[0] = k_rollout_grad<M, PHNN_INTEG_EULER, true>;
+  g.grad_stash[1] = k_rollout_grad<M, PHNN_INTEG_RK4, true>;
   g.lds_floats = M::IMG + 4 * M::SCR + kXchFloats;
   return g;
 }

@@ -71,7 +71,7 @@ using M_CANON_128_H_MFULL = CanonModel<128, MM_F16X2, 1, MASS_FULL>;
 
 struct GradSet {
   void (*grad[2])(RollParams);     // Euler, RK4: recompute the tape
-  void (*grad_stash)(RollParams);  // Euler, K2 reads the tape K1 stashed
+  void (*grad_stash[2])(RollParams);  // Euler, RK4: K2 reads the tape(s) K1 stashed
   void (*mvjp)(PointParams);
 };
 
@@ -84,8 +84,8 @@ bool phnn_grad_kernels(int variant, GradSet* g);
 struct SplitSet {
   void (*fwd[2])(RollParams);
   void (*grad[2])(RollParams);
-  void (*fwd_stash)(RollParams);
-  void (*grad_stash)(RollParams);
+  void (*fwd_stash[2])(RollParams);   // Euler, RK4
+  void (*grad_stash[2])(RollParams);
   int lds_floats;  // image + 4 x per-wave scratch + exchange area
 };
 bool phnn_split_kernels(int variant, SplitSet* g);  // false: no split-tile kernels for this variant

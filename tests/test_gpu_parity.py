@@ -188,26 +188,29 @@ def test_errors(torch_cuda):
         RolloutEngine(deep)
 
 
-def test_stash_and_recompute_modes_agree(bundle):
-    """K2 fed by K1's activation stash (default, Euler) vs K2 recomputing the forward tape: same gradients."""
+@pytest.mark.parametrize("integ", ["euler", "rk4"])
+def test_stash_and_recompute_modes_agree(bundle, integ):
+    """K2 fed by K1's activation stash (default; RK4: four stage tapes + stage states per step) vs K2 recomputing the
+    forward tape(s): same costs, same gradients."""
     name, g, m64, eng = bundle
     rng = np.random.default_rng(21)
     B, H, n = 333, 40, eng.n
     x0 = (rng.uniform(-1, 1, size=(B, n)) * 0.4).astype(np.float32)
     U = rng.uniform(-1, 1, size=(B, H, 1)).astype(np.float32) * float(g["u_max"])
     cost = ol.cost_from_golden(g)
-    assert eng.use_stash and eng.workspace_bytes(B, H, "euler") > 0 and eng.workspace_bytes(B, H, "rk4") == 0
-    c1, g1, x1 = [npy(t).copy() for t in eng.rollout_cost_grad(x0, U, cost, "euler", float(g["dt"]), want_grad_x0=True)]
+    assert eng.use_stash and 0 < eng.workspace_bytes(B, H, "euler") < eng.workspace_bytes(B, H, "rk4")
+    c1, g1, x1 = [npy(t).copy() for t in eng.rollout_cost_grad(x0, U, cost, integ, float(g["dt"]), want_grad_x0=True)]
     eng.use_stash = False
     try:
-        c2, g2, x2 = [npy(t).copy() for t in eng.rollout_cost_grad(x0, U, cost, "euler", float(g["dt"]), want_grad_x0=True)]
+        c2, g2, x2 = [npy(t).copy() for t in eng.rollout_cost_grad(x0, U, cost, integ, float(g["dt"]), want_grad_x0=True)]
     finally:
         eng.use_stash = True
     assert np.array_equal(c1, c2)
     gmax = np.abs(g2).max(axis=(1, 2), keepdims=True)
     assert np.all(np.abs(g1 - g2) <= 1e-6 * gmax) and np.allclose(x1, x2, rtol=1e-5, atol=1e-6 * np.abs(x2).max())
-    ref = m64.rollout(x0, U, cost, "euler", float(g["dt"]), nthreads=8)
+    ref = m64.rollout(x0, U, cost, integ, float(g["dt"]), nthreads=8)
     assert np.all(np.abs(g2 - ref["grad_u"]) <= 1e-4 * np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True))
+    assert np.all(np.abs(g1 - ref["grad_u"]) <= 1e-4 * np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True))
 
 
 @pytest.mark.parametrize("name", ["phnn_cartpole", "canonical_cartpole"])
