@@ -39,6 +39,11 @@ for name, k in (("K1", "fwd"), ("K2", "grad")):
 out["note"] = ("separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --steps 3 (f16x2 kernels, stash = a2, q1, dH); "
                "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halves wide streaming reads)")
 json.dump(out, open(os.path.join(dst, "traffic_measured.json"), "w"), indent=1)
+for tag in ("wgrad", "rk4"):  # per-kernel stats of the training pass (f4) and of config 5 on the RK4 stash
+    m = glob.glob(os.path.join(src, f"trace_{tag}/**/*kernel_stats.csv"), recursive=True)
+    if m:
+        shutil.copy(m[0], os.path.join(dst, f"{prefix}_{tag}_kernel_stats.csv"))
+        shutil.copy(os.path.join(src, f"{tag}_probe.txt"), os.path.join(dst, f"{prefix}_{tag}_probe.txt"))
 for a, b in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"), ("other_configs.jsonl", "_other_configs.jsonl")):
     shutil.copy(os.path.join(src, a), os.path.join(dst, prefix + b))
 print(json.dumps(out, indent=1))
