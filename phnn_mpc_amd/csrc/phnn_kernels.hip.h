@@ -2455,11 +2455,32 @@ struct IsPhnn { static constexpr bool value = false; };
 template <int N, int HID, bool FIXG, int MM, int MI>
 struct IsPhnn<PhnnModel<N, HID, FIXG, MM, MI>> { static constexpr bool value = true; };
 
-// exchange geometry of k_wgrad_reduce (shared with the host's LDS size): k columns of the B-side array and floats per buffer
+// geometry of k_wgrad_reduce (shared with the host's LDS size).  Staged constants: only the small vectors of each net
+// (H_net: W1 fragments, b1 ... b3; R_net / G_net: V1 fragments, c1, c2, scale).  Exchange buffer (floats).
 template <class M>
-constexpr int kWgKA = 32 + (IsPhnn<M>::value ? 16 : 0) + (IsPhnn<M>::value && M::Rec::oSmall / M::Rec::VEC == 6 ? 16 : 0);
-template <class M>
-constexpr int kWgXchFloats = M::HID * 36 + M::HID * (kWgKA<M> + 4) + 32 * 20;
+struct WgGeom {
+  static constexpr bool PHNN = IsPhnn<M>::value;
+  static constexpr bool GNET = PHNN && M::Rec::oSmall / M::Rec::VEC == 6;
+  using YH = LayH2<M::HID, M::MM>;
+  using Y1 = LayH1<M::HID, M::MM>;
+  static constexpr int H0 = YH::oW1f, HN = YH::SIZE - YH::oW1f;          // staged range of the H_net image
+  static constexpr int R0 = Y1::oV1f, RN = Y1::oSc + 4 - Y1::oV1f;        // staged range of an R_net / G_net image
+  static constexpr int KEEP = HN + (PHNN ? RN : 0) + (GNET ? RN : 0);
+  static constexpr int PARTW = M::HID * 16;                               // dwords per bf16 part: [HID rows][32 k] bf16
+  static constexpr int LDH = (PHNN ? 16 : 0) + (GNET ? 16 : 0) + 4;        // floats per row of the hidden-activation array
+  static constexpr int oXA = 3 * PARTW, oXH = 6 * PARTW, oXO = oXH + M::HID * LDH;
+  static constexpr int XCH = oXO + 32 * 20;
+  static constexpr int LDS_FLOATS = KEEP + 2 * XCH;
+};
+
+// f32 pair -> three packed bf16 pairs (hi, mid, lo; x = hi + mid + lo to 2^-24), low half = first value
+DEV void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = pk_bf16(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = pk_bf16(r0, r1);
+  const float t0 = r0 - __builtin_bit_cast(float, m << 16), t1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = pk_bf16(t0, t1);
+}
 
 // one-hidden-layer net (R_net / G_net) part of a record, for the units of this lane: the vector-shaped sums.  (The
 // output layer's matrix-shaped gradient V2bar = sum obar (x) h goes through the MFMA path with W2bar.)
@@ -2505,20 +2526,30 @@ struct H1Acc {
   }
 };
 
-// one wave's slice of a record: its unit tile of every big vector + the small vectors of its lane's rollout
+// one wave's slice of a record: its unit tile of every big vector + what its lane needs of the small vectors of its
+// rollout: x, v, lam, dH, the quarter 4q .. 4q+3 of rbar, u and Hbar (25 dwords instead of the block's 40)
 template <int NB>
 struct RecSlice {
-  f32x4 big[NB], sm[10];
+  f32x4 big[NB], x, v, lam, dH, rv, uu;
+  float Hbar;
   DEV void load(const float* R, int vec4, int oSmall, int w, Lane ln) {
     const f32x4* bg = reinterpret_cast<const f32x4*>(R) + w * 64 + ln.lane;
 #pragma unroll
     for (int k = 0; k < NB; ++k) big[k] = bg[k * vec4];
     const f32x4* s4 = reinterpret_cast<const f32x4*>(R + oSmall + ln.i * kRecSmall);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) sm[k] = s4[k];
+    x = s4[0];
+    v = s4[1];
+    lam = s4[2];
+    dH = s4[3];
+    rv = s4[4 + ln.q];
+    uu = s4[8];
+    Hbar = R[oSmall + ln.i * kRecSmall + 36];
   }
 };
 
+#ifndef PHNN_RED_ORDER
+#define PHNN_RED_ORDER 0
+#endif
 template <class M>
 __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2526,17 +2557,19 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   using Y = LayH2<HID, MM>;
   using Rec = typename M::Rec;
   using BL = BlobOf<M>;
-  constexpr bool PHNN = IsPhnn<M>::value;
-  constexpr bool GNET = PHNN && Rec::oSmall / Rec::VEC == 6;
-  // the hidden x hidden image (the first W2F floats of every model image) is not needed here: stage the rest
-  constexpr int SKIP = Y::W2F, KEEP = M::IMG - SKIP;
+  using GE = WgGeom<M>;
+  constexpr bool PHNN = GE::PHNN, GNET = GE::GNET;
   static_assert(M::oH == 0 && Y::oW2 == 0, "the W2 image leads the model image");
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(p.img + SKIP);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-    for (int k = threadIdx.x; k < KEEP / 4; k += blockDim.x) dst[k] = src[k];
+  // stage the small constants of each net (the 128 x 128 images are not needed here)
+  for (int k = threadIdx.x; k < GE::HN; k += blockDim.x) lds[k] = p.img[M::oH + GE::H0 + k];
+  if constexpr (PHNN) {
+    for (int k = threadIdx.x; k < GE::RN; k += blockDim.x) lds[GE::HN + k] = p.img[M::oR + GE::R0 + k];
+    if constexpr (GNET)
+      for (int k = threadIdx.x; k < GE::RN; k += blockDim.x) lds[GE::HN + GE::RN + k] = p.img[M::oGn + GE::R0 + k];
   }
-  const float* L = lds - SKIP;  // image offsets stay valid for everything behind the W2 image
+  const float* L = lds - GE::H0;                       // L[Y::o...] valid for the staged H_net range
+  const float* LR = lds + GE::HN - GE::R0;             // LR[LayH1::o...] valid for the staged R_net range
+  const float* LG = lds + GE::HN + GE::RN - GE::R0;    // G_net
   const int w = threadIdx.x >> 6;
   Lane ln;
   ln.lane = threadIdx.x & 63;
@@ -2544,15 +2577,21 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   ln.q = ln.lane >> 4;
   ln.w = 0;
   ln.xch = nullptr;
-  // Exchange buffers (x2, ping-pong), all f32, the k index = rollout (16 per segment), stored so that lane (i,q) finds
-  // the operands of its k-steps contiguously:
-  //   XG [HID units][32 k]      gdot2* | g2            A operand of W2bar (rows of this wave)
-  //   XA [HID units][32+16+16]  a1 | adot1 | hR | hG   B operands (W2bar: 32 k; V2bar of R_net / G_net: 16 k each)
-  //   XO [32 rows][16 k]        rbar (rows 0..15) | gbar (rows 16..31)   A operands of the V2bars
-  // 32-k segment: k at position (k & 3) * 8 + (k >> 2); 16-k segments: (k & 3) * 4 + (k >> 2).
-  constexpr int KA = kWgKA<M>, LDG = 36, LDA = KA + 4, LDO = 20;
-  constexpr int XSZ = kWgXchFloats<M>;
-  float* X = lds + KEEP;
+  // Exchange buffers (x2, ping-pong).  The matrix-shaped gradient W2bar = sum_points gdot2* (x) a1 + g2 (x) adot1 is a
+  // GEMM with K = points; per record K = 32 (16 rollouts x 2 terms), one v_mfma_f32_16x16x32_bf16 k-depth.  The
+  // factors go through LDS as three bf16 pieces each (x = hi + mid + lo to 2^-24; bf16 keeps the f32 exponent range,
+  // cotangents can be arbitrarily small) and every 16 x 16 output tile takes the six significant cross products:
+  //   XG [3 parts][HID rows][32 k] bf16   k = 2 rollout + term: (gdot2*, g2)      A operand (rows of this wave)
+  //   XA [3 parts][HID rows][32 k] bf16   (a1, adot1)                               B operand (all rows)
+  //   XH [HID rows][16 (+16) k] f32       hR [| hG], k at position (k & 3) * 4 + (k >> 2)   B operands of the V2bars
+  //   XO [32 rows][16 k] f32              rbar (rows 0..15) | gbar (rows 16..31)            A operands of the V2bars
+  // Bank layout of the bf16 arrays (64-byte rows, no padding): rows of a 16-row group are stored permuted, row 4q + r
+  // at slot s = 4r + q, and the 16-byte chunk c of a row at chunk c ^ ((s >> 2) & 3).  Writes (one dword per lane):
+  // the four q-lanes of a rollout hit four adjacent rows = all 64 banks once.  Reads (ds_read_b128, 16 lanes per
+  // pass): the 16 rows of a pass fall on 16 different 16-byte bank groups.  (Plain 64-byte rows: 4-way conflicts on
+  // one side or the other -- measured 1.4 ms of the kernel's 3.4.)
+  constexpr int LDH = GE::LDH, LDO = 20, PARTW = GE::PARTW;
+  float* X = lds + GE::KEEP;
   __syncthreads();
   const float S = 2.8853900817779268f / L[Y::oB3 + 1], k1inv = L[Y::oB3 + 2], Sb = L[Y::oB3 + 3];
   const float c_ad2 = k1inv / S, c_q1 = 1.0f / (S * Sb), c_qd = -2.0f * k1inv / (S * Sb);
@@ -2568,19 +2607,18 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   H1Acc<N, HID, MM, PHNN ? N * N : 1> accR;
   H1Acc<N, HID, MM, N * M::MI> accG;
 
-  // Records are streamed once and every iteration ends in a workgroup barrier: the next record's slice of this wave
-  // (NBIG + 10 float4) is loaded before the current one is processed, so that its HBM round trip overlaps the work.
+  // Records are streamed once.  Per record: (1) "stage" -- the element-wise algebra of this wave's units (vector-shaped
+  // sums stay in registers) and the transposition of the GEMM factors into exchange buffer `buf`; workgroup barrier;
+  // (2) "gemm" -- the matrix-shaped sums from that buffer.  The loop is software-pipelined: an iteration runs gemm of
+  // the previous record and stage of the current one (different buffers, no dependence, one basic block -- MFMA / LDS
+  // reads and VALU overlap), then the barrier; the slice of the record after that (NBIG + 10 float4 per lane) is
+  // already in flight, so its HBM round trip is covered too.
   constexpr int NB = Rec::oSmall / Rec::VEC;
-  RecSlice<NB> nxt;
-  if ((long long)blockIdx.x < p.n_rec) nxt.load(p.rec + (long long)blockIdx.x * Rec::SIZE, Rec::VEC / 4, Rec::oSmall, w, ln);
-  int buf = 0;
-  for (long long r = blockIdx.x; r < p.n_rec; r += gridDim.x, buf ^= 1) {
-    const RecSlice<NB> cur = nxt;
-    if (r + (long long)gridDim.x < p.n_rec)
-      nxt.load(p.rec + (r + (long long)gridDim.x) * Rec::SIZE, Rec::VEC / 4, Rec::oSmall, w, ln);
+  const int p16 = (ln.i & 3) * 4 + (ln.i >> 2);  // position of k = rollout i in a 16-k segment
+  auto stage = [&](const RecSlice<NB>& cur, int buf) {
     const f32x4 a2 = cur.big[0], q1r = cur.big[1], ad2r = cur.big[2], qdr = cur.big[3];
-    const f32x4 x = cur.sm[0], v = cur.sm[1], lam = cur.sm[2], dH = cur.sm[3], uu = cur.sm[8];
-    const float Hbar = cur.sm[9][0];
+    const f32x4 x = cur.x, v = cur.v, lam = cur.lam, dH = cur.dH, uu = cur.uu;
+    const float Hbar = cur.Hbar;
     // H_net factors of this lane's 4 units
     const f32x4 a1 = tanh4_model<T>(mfma(w1f, sel4(x, ln.q), b1v));
     const f32x4 d1 = dtanh(a1), d2 = dtanh(a2);
@@ -2596,32 +2634,29 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     aB1 += gd1;
 #pragma unroll
     for (int k = 0; k < N; ++k) aW1[k] += gd1 * x[k] + g1 * v[k];
-    float* XG = X + buf * XSZ;
-    float* XA = XG + HID * LDG;
-    float* XO = XA + HID * LDA;
-    const int p16 = (ln.i & 3) * 4 + (ln.i >> 2);  // position of k = rollout i in a 16-k segment
+    unsigned* XG = reinterpret_cast<unsigned*>(X + buf * GE::XCH);
+    unsigned* XA = XG + GE::oXA;
+    float* XH = X + buf * GE::XCH + GE::oXH;
+    float* XO = X + buf * GE::XCH + GE::oXO;
     f32x4 hR = splat4(0.f), hG = splat4(0.f);
-    if (w == 0) {
-      aB3 += Hbar;
-      if (PHNN) {  // lane (i,q) keeps row q of Jbar
-        const float lq = sel4(lam, ln.q), hq = sel4(dH, ln.q);
+    // per-rollout sums: every wave forms them (no branch in the loop body), wave 0 writes them at the end
+    aB3 += Hbar;
+    if (PHNN) {  // lane (i,q) keeps row q of Jbar
+      const float lq = sel4(lam, ln.q), hq = sel4(dH, ln.q);
 #pragma unroll
-        for (int j = 0; j < N; ++j) aJ[j] += lq * dH[j] - lam[j] * hq;
-      } else {
-        aRd[0] += cur.sm[4][2];
-        aRd[1] += cur.sm[4][3];
-      }
+      for (int j = 0; j < N; ++j) aJ[j] += lq * dH[j] - lam[j] * hq;
+    } else {
+      aRd[0] += cur.rv[2];  // lanes q = 0 hold small vector 4 (the R_diag cotangents); only lane 0's sum is written
+      aRd[1] += cur.rv[3];
     }
     if constexpr (PHNN) {
       // output cotangents 4q .. 4q+3 of this lane's rollout: rbar = small vectors 4.., gbar[i][k] = lam[i] u[k]
-      f32x4 rv = splat4(0.f), gv = splat4(0.f);
+      // (every wave writes the same values to XO: identical stores, no branch)
+      f32x4 gv = splat4(0.f);
+      const f32x4 rv = (4 * ln.q < N * N) ? cur.rv : splat4(0.f);
+      hR = accR.add(LR, w, ln, x, cur.big[4], rv);
 #pragma unroll
-      for (int k = 0; k < (N * N + 3) / 4; ++k) rv = (ln.q == k) ? cur.sm[4 + k] : rv;
-      hR = accR.add(L + M::oR, w, ln, x, cur.big[4], rv);
-      if (w == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) XO[(4 * ln.q + e) * LDO + p16] = rv[e];
-      }
+      for (int e = 0; e < 4; ++e) XO[(4 * ln.q + e) * LDO + p16] = rv[e];
       if constexpr (GNET) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -2629,52 +2664,135 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
           for (int i = 0; i < N; ++i)
 #pragma unroll
             for (int k = 0; k < M::MI; ++k) gv[e] = (4 * ln.q + e == i * M::MI + k) ? lam[i] * uu[k] : gv[e];
-        hG = accG.add(L + M::oGn, w, ln, x, cur.big[5], gv);
-        if (w == 0) {
+        hG = accG.add(LG, w, ln, x, cur.big[5], gv);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) XO[(16 + 4 * ln.q + e) * LDO + p16] = gv[e];
+        for (int e = 0; e < 4; ++e) XO[(16 + 4 * ln.q + e) * LDO + p16] = gv[e];
+      }
+    }
+    // transpose the factors through LDS: rollout index -> k index
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      // unit 16w + 4q + rr, k = 2i, 2i + 1: row slot 4rr + q, 16-byte chunk (i >> 2) ^ rr
+      const int slot = (16 * w + 4 * rr + ln.q) * 16 + ((((ln.i >> 2) ^ rr) << 2) | (ln.i & 3));
+      unsigned h, m, l;
+      split3_pair(gd2[rr], g2[rr], h, m, l);
+      XG[slot] = h;
+      XG[PARTW + slot] = m;
+      XG[2 * PARTW + slot] = l;
+      split3_pair(a1[rr], ad1[rr], h, m, l);
+      XA[slot] = h;
+      XA[PARTW + slot] = m;
+      XA[2 * PARTW + slot] = l;
+      const int unit = 16 * w + 4 * ln.q + rr;
+      if (PHNN) XH[unit * LDH + p16] = hR[rr];
+      if (GNET) XH[unit * LDH + 16 + p16] = hG[rr];
+    }
+  };
+  auto gemm = [&](int buf) {
+    const unsigned* XG = reinterpret_cast<const unsigned*>(X + buf * GE::XCH);
+    const unsigned* XA = XG + GE::oXA;
+    const float* XH = X + buf * GE::XCH + GE::oXH;
+    const float* XO = X + buf * GE::XCH + GE::oXO;
+    // rows 16w.. of W2bar: A = XG[16w + i][8q .. 8q+7], B = XA[16nt + i][8q .. 8q+7]
+    const int rslot = ((ln.i & 3) * 4 + (ln.i >> 2)) * 16 + ((ln.q ^ (ln.i & 3)) << 2);  // row i of a group, chunk of k = 8q
+    bf16x8 ag[3];
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+      ag[part] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(XG + part * PARTW + 16 * w * 16 + rslot));
+    // column tiles in pairs, the next pair's fragments requested before this pair's MFMAs (LDS latency, not LDS
+    // bandwidth, is what this phase waits on); the two tiles of a pair alternate so that dependent MFMAs are two apart
+    auto bfrag = [&](int nt, bf16x8 (&bb)[3]) {
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        bb[part] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(XA + part * PARTW + 16 * nt * 16 + rslot));
+    };
+    bf16x8 b0[3], b1[3];
+    bfrag(0, b0);
+    bfrag(1, b1);
+#pragma unroll
+    for (int np = 0; np < T; np += 2) {
+      bf16x8 c0[3], c1[3];
+      if (np + 2 < T) {
+        bfrag(np + 2, c0);
+        bfrag(np + 3, c1);
+      }
+      f32x4 o0 = accW2[np], o1 = accW2[np + 1];  // smallest terms first
+      o0 = mfma_bf(ag[2], b0[0], o0);
+      o1 = mfma_bf(ag[2], b1[0], o1);
+      o0 = mfma_bf(ag[0], b0[2], o0);
+      o1 = mfma_bf(ag[0], b1[2], o1);
+      o0 = mfma_bf(ag[1], b0[1], o0);
+      o1 = mfma_bf(ag[1], b1[1], o1);
+      o0 = mfma_bf(ag[1], b0[0], o0);
+      o1 = mfma_bf(ag[1], b1[0], o1);
+      o0 = mfma_bf(ag[0], b0[1], o0);
+      o1 = mfma_bf(ag[0], b1[1], o1);
+      o0 = mfma_bf(ag[0], b0[0], o0);
+      o1 = mfma_bf(ag[0], b1[0], o1);
+      accW2[np] = o0;
+      accW2[np + 1] = o1;
+      if (np + 2 < T) {
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          b0[part] = c0[part];
+          b1[part] = c1[part];
         }
       }
     }
-    // transpose the factors through LDS: [unit][position of k], k = rollout
-    const int p1 = (ln.i & 3) * 8 + (ln.i >> 2), p2 = p1 + 4;  // positions of k = i and k = 16 + i in the 32-k segment
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int unit = 16 * w + 4 * ln.q + rr;
-      XG[unit * LDG + p1] = gd2[rr];
-      XG[unit * LDG + p2] = g2[rr];
-      XA[unit * LDA + p1] = a1[rr];
-      XA[unit * LDA + p2] = ad1[rr];
-      if (PHNN) XA[unit * LDA + 32 + p16] = hR[rr];
-      if (GNET) XA[unit * LDA + 48 + p16] = hG[rr];
-    }
-    __syncthreads();
-    // rows 16w.. of W2bar: A = XG[16w + i][k], B = XA[16nt + i][k], k-step s <-> k = 4s + q <-> position 8q + s
-    const f32x4* ga = reinterpret_cast<const f32x4*>(XG + (16 * w + ln.i) * LDG + 8 * ln.q);
-    const f32x4 g0 = ga[0], g1v = ga[1];
-#pragma unroll
-    for (int nt = 0; nt < T; ++nt) {
-      const f32x4* ba = reinterpret_cast<const f32x4*>(XA + (16 * nt + ln.i) * LDA + 8 * ln.q);
-      const f32x4 b0 = ba[0], b1 = ba[1];
-      f32x4 acc = accW2[nt];
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc = mfma(g0[s2], b0[s2], acc);
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) acc = mfma(g1v[s2], b1[s2], acc);
-      accW2[nt] = acc;
-    }
     if constexpr (PHNN) {  // V2bar[o][16w + i] += sum_k obar[o][k] h[16w + i][k]   (k-step s <-> k = 4s + q <-> position 4q + s)
       const f32x4 oa = *reinterpret_cast<const f32x4*>(XO + ln.i * LDO + 4 * ln.q);
-      const f32x4 hb4 = *reinterpret_cast<const f32x4*>(XA + (16 * w + ln.i) * LDA + 32 + 4 * ln.q);
+      const f32x4 hb4 = *reinterpret_cast<const f32x4*>(XH + (16 * w + ln.i) * LDH + 4 * ln.q);
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) accR.V2 = mfma(oa[s2], hb4[s2], accR.V2);
       if constexpr (GNET) {
         const f32x4 og = *reinterpret_cast<const f32x4*>(XO + (16 + ln.i) * LDO + 4 * ln.q);
-        const f32x4 hg4 = *reinterpret_cast<const f32x4*>(XA + (16 * w + ln.i) * LDA + 48 + 4 * ln.q);
+        const f32x4 hg4 = *reinterpret_cast<const f32x4*>(XH + (16 * w + ln.i) * LDH + 16 + 4 * ln.q);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) accG.V2 = mfma(og[s2], hg4[s2], accG.V2);
       }
     }
+  };
+  const long long G = gridDim.x, last = p.n_rec - 1;
+  auto slice_of = [&](long long r) { return p.rec + (r < last ? r : last) * Rec::SIZE; };  // clamped: a prefetch past the end re-reads the last record
+  if ((long long)blockIdx.x < p.n_rec) {
+    long long r = blockIdx.x;
+    RecSlice<NB> cur, nxt;
+    cur.load(slice_of(r), Rec::VEC / 4, Rec::oSmall, w, ln);
+    nxt.load(slice_of(r + G), Rec::VEC / 4, Rec::oSmall, w, ln);
+    stage(cur, 0);
+    __syncthreads();
+    int buf = 0;
+    for (r += G; r < p.n_rec; r += G, buf ^= 1) {
+      cur = nxt;
+      nxt.load(slice_of(r + G), Rec::VEC / 4, Rec::oSmall, w, ln);
+      // the two waves of a SIMD (w and w + T/2) run the two halves in opposite order: one streams MFMAs while the
+      // other does vector work
+#if PHNN_RED_ORDER == 0
+      gemm(buf);
+      stage(cur, buf ^ 1);
+#elif PHNN_RED_ORDER == 3
+      gemm(buf);
+      stage(cur, buf ^ 1);
+#pragma unroll
+      for (int k = 0; k < 6 * T + 8; ++k) {  // one MFMA per PHNN_RED_VPM vector instructions
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, PHNN_RED_VPM, 0);
+      }
+#elif PHNN_RED_ORDER == 1
+      stage(cur, buf ^ 1);
+      gemm(buf);
+#else
+      if (w < T / 2) {
+        gemm(buf);
+        stage(cur, buf ^ 1);
+      } else {
+        stage(cur, buf ^ 1);
+        gemm(buf);
+      }
+#endif
+      __syncthreads();
+    }
+    gemm(buf);
   }
   // ---- write this workgroup's partial gradient (every entry of its row that carries a gradient)
   float* row = p.slab + (long long)blockIdx.x * p.PP;
@@ -2716,8 +2834,8 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     if (w == 0 && ln.lane == 0) {
       row[BL::oRd + 0] = 0.f;  // rows 0, 1 of R multiply the dq rows the reference discards: zero gradient
       row[BL::oRd + 1] = 0.f;
-      row[BL::oRd + 2] = t2 * L[M::oC + 10];
-      row[BL::oRd + 3] = t3 * L[M::oC + 11];
+      row[BL::oRd + 2] = t2 * p.img[M::oC + 10];
+      row[BL::oRd + 3] = t3 * p.img[M::oC + 11];
     }
   }
 }

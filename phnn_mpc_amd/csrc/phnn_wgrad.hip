@@ -18,7 +18,7 @@ static WgradSet wgrad_set() {
   g.blob_floats = BlobOf<M>::SIZE;
   g.reduce_waves = M::T;
   using Y = LayH2<M::HID, M::MM>;
-  g.reduce_lds_bytes = (int)sizeof(float) * ((M::IMG - Y::W2F) + 2 * kWgXchFloats<M>);
+  g.reduce_lds_bytes = (int)sizeof(float) * WgGeom<M>::LDS_FLOATS;
   return g;
 }
 
