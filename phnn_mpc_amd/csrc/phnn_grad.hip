@@ -1,7 +1,7 @@
 // phnn_grad.hip -- instantiates the adjoint kernels (K2 and the single-call VJP) of every variant.  A translation
-// unit of its own because these kernels want another instruction scheduler than the forward ones: with
-// -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-use-amdgpu-trackers=1 K2 is 3 % faster and K1 up to 5 % slower
-// (same arithmetic, same results), so the Makefile passes those flags to this file only.  It also lets the two halves compile in parallel.
+// unit of its own so that the halves compile in parallel, and so that scheduler flags can be tried on the adjoint
+// kernels alone (Makefile: GRAD_SCHED; round 1 shipped max-ILP here, round 2 builds every unit with the default
+// scheduler -- DESIGN.md section 9).
 #define PHNN_ADJOINT_UNIT
 #include "phnn_variants.h"
 
