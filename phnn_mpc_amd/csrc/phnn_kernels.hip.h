@@ -224,6 +224,7 @@ DEV void sq_bwd(Act<TO>& o, const float* W, Lane ln, const Act<TI>& in) {
 // [tile 2s regs 0..3, tile 2s+1 regs 0..3] as the 8 bf16 of its B fragment, i.e. k-slot 8q+j <-> unit
 // 32s + (j<4 ? 4q+j : 16+4q+j-4); the weight images are stored with the same permutation of their columns.
 // ------------------------------------------------------------------------------------------------
+constexpr int MM_F32 = 0, MM_BF16X3 = 1, MM_F16X2 = 2;  // how the hidden x hidden products are evaluated
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -422,6 +423,41 @@ struct HfImg {  // 2 parts [HID rows][RS f16], same row stride and column permut
   static constexpr int FLOATS = 2 * PART / 4;
 };
 
+// f16x2 input layer: in(<=4) -> 16T units with all four split products of W x in ONE v_mfma_f32_16x16x32_f16 per
+// tile (8 issue cycles instead of the f32 MFMA's 32).  B fragment of every lane: [hi(x0..3), lo(x0..3)] of its rollout.
+// A fragment image [T][64] x 8 halves: lane (i,0) holds [hi(W[u][0..3]), hi(W[u][0..3])], lane (i,1) the same of lo(W),
+// lanes q >= 2 zeros -- k-slots 0..7 give W_hi (x_hi + x_lo), 8..15 W_lo (x_hi + x_lo).  f16 denormals are honoured by
+// the matrix pipe (tools/probe_f16_denorm.hip), so small inputs keep an absolute error <= 2^-25.
+DEV f16x8 in_frag_h(f32x4 x) {
+  f32x2 v01 = {x[0], x[1]}, v23 = {x[2], x[3]};
+  f16x2 h01 = __builtin_convertvector(v01, f16x2), h23 = __builtin_convertvector(v23, f16x2);
+  f32x2 r01 = residual_h(h01, v01), r23 = residual_h(h23, v23);
+  u32x4 B = {__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23),
+             __builtin_bit_cast(unsigned, __builtin_convertvector(r01, f16x2)),
+             __builtin_bit_cast(unsigned, __builtin_convertvector(r23, f16x2))};
+  return __builtin_bit_cast(f16x8, B);
+}
+constexpr int kInFragH(int T) { return T * 64 * 4; }  // floats of the f16 fragment image
+template <int T>
+DEV void in_layer_h(Act<T>& o, const float* Wh, Lane ln, f16x8 xf) {
+  keep_lds_reads_local();
+#pragma unroll
+  for (int nt = 0; nt < T; ++nt) o.v[nt] = mfma_h(*reinterpret_cast<const f16x8*>(Wh + (nt * 64 + ln.lane) * 4), xf, o.v[nt]);
+}
+// the input layer of a net in product mode MM: f32 fragment image at oF, f16 fragment image at oFh (f16x2 only).
+// SITE: which call site; PHNN_INH_MASK selects the sites that use the f16 form.  Default: everywhere except the hidden
+// layer of R_net / G_net inside the adjoint (kInHNet1Adj): with it the headline adjoint kernel spills 120 B per lane
+// (measured: every site f16 = K1 -3.8 %, K2 +7 %; this mask = K1 -2.5 %, K2 -0.6 %).
+constexpr int kInHFwd = 1, kInHRecomp = 2, kInHHvp = 4, kInHNet1 = 8, kInHNet1Adj = 16;
+#ifndef PHNN_INH_MASK
+#define PHNN_INH_MASK (kInHFwd | kInHRecomp | kInHHvp | kInHNet1)
+#endif
+template <int T, int MM, int SITE>
+DEV void in_layer_mm(Act<T>& o, const float* Lnet, int oF, int oFh, Lane ln, f32x4 x, int tile0 = 0) {
+  if constexpr (MM == MM_F16X2 && (PHNN_INH_MASK & SITE) != 0) in_layer_h<T>(o, Lnet + oFh + tile0 * 256, ln, in_frag_h(x));
+  else in_layer<T>(o, Lnet + oF + tile0 * 64, ln, sel4(x, ln.q));
+}
+
 DEV void mfma3x2(f32x4& o0, f32x4& o1, const f16x8 (&a)[2][2], f16x8 xh, f16x8 xl) {
   o0 = mfma_h(a[0][1], xh, o0);
   o1 = mfma_h(a[1][1], xh, o1);
@@ -576,14 +612,14 @@ DEV float reduce_q(float v) {  // sum over the 4 lanes (q = 0..3) of a rollout
 // ------------------------------------------------------------------------------------------------
 // LDS image layouts (offsets in floats; every section size is a multiple of 4 floats)
 // ------------------------------------------------------------------------------------------------
-constexpr int MM_F32 = 0, MM_BF16X3 = 1, MM_F16X2 = 2;  // how the hidden x hidden products are evaluated
 
 template <int HID, int MM = MM_F32>
 struct LayH2 {  // in(<=4) -> HID -> HID -> 1  (H_net)
   static constexpr int T = HID / 16, LD = HID + 4, LR = HID + 8;
   static constexpr int oW2 = 0;                  // f32: [HID][LD]; bf16x3 / f16x2: BfImg / HfImg (x S for f16x2)
   static constexpr int W2F = MM == MM_F32 ? HID * LD : (MM == MM_BF16X3 ? BfImg<HID>::FLOATS : HfImg<HID>::FLOATS);
-  static constexpr int oW1f = oW2 + W2F;         // [T][64] fragment image of W1
+  static constexpr int oW1h = oW2 + W2F;         // f16x2: [T][64] x 8 halves, f16 fragment image of W1 (in_layer_h)
+  static constexpr int oW1f = oW1h + (MM == MM_F16X2 ? T * 64 * 4 : 0);  // [T][64] f32 fragment image of W1
   static constexpr int oB1 = oW1f + T * 64;      // [HID]
   static constexpr int oB2 = oB1 + HID;          // [HID]   b2 * S
   static constexpr int oW3 = oB2 + HID;          // [HID]   w3 (Hamiltonian value)
@@ -604,7 +640,8 @@ struct LayH1 {  // in(<=4) -> HID -> out(<=16)  (R_net, G_net)
   static constexpr int oV2 = 0;                 // f32: [16][LD];  f16x2: forward image (hi, lo) of Sr * V2 ...
   static constexpr int oV2T = oV2 + 2 * FPART / 4;  // ... then the transposed image (hi, lo) of Sr * V2^T
   static constexpr int V2F = HF ? (2 * FPART + 2 * BPART) / 4 : 16 * LD;
-  static constexpr int oV1f = oV2 + V2F;        // [T][64]
+  static constexpr int oV1h = oV2 + V2F;        // f16x2: f16 fragment image of V1 (in_layer_h)
+  static constexpr int oV1f = oV1h + (HF ? T * 64 * 4 : 0);  // [T][64]
   static constexpr int oC1 = oV1f + T * 64;     // [HID]
   static constexpr int oC2 = oC1 + HID;         // [16]
   static constexpr int oSc = oC2 + 16;          // [4] (1 / Sr, 0, 0, 0)
@@ -655,12 +692,12 @@ struct HTape {
   Act<HID / 16> a1, a2, q1;  // activations, and q1 = W2^T g2 (before the (1-a1^2) factor)
 };
 
-template <int HID, bool WANT_H, int MM = MM_F32>
+template <int HID, bool WANT_H, int MM = MM_F32, int SITE = kInHFwd>
 DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hval) {
   using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(tp.a1, L + Y::oB1, ln);
-  in_layer<T>(tp.a1, L + Y::oW1f, ln, sel4(z, ln.q));
+  in_layer_mm<T, MM, SITE>(tp.a1, L, Y::oW1f, Y::oW1h, ln, z);
   tanh_act_pre<T>(tp.a1);
   load_vec<T>(tp.a2, L + Y::oB2, ln);
   if (MM == MM_BF16X3) {
@@ -727,7 +764,7 @@ template <int HID, int MM>
 DEV void hnet_layer1(const float* L, Lane ln, f32x4 z, Act<HID / 16>& a1) {
   using Y = LayH2<HID, MM>;
   load_vec<Y::T>(a1, L + Y::oB1, ln);
-  in_layer<Y::T>(a1, L + Y::oW1f, ln, sel4(z, ln.q));
+  in_layer_mm<Y::T, MM, kInHRecomp>(a1, L, Y::oW1f, Y::oW1h, ln, z);
   tanh_act_pre<Y::T>(a1);
 }
 
@@ -748,7 +785,7 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v, float* rec 
   }
   Act<T> ad1, w;
   zero_act<T>(ad1);
-  in_layer<T>(ad1, L + Y::oW1f, ln, sel4(v, ln.q));
+  in_layer_mm<T, MM, kInHHvp>(ad1, L, Y::oW1f, Y::oW1h, ln, v);
 #pragma unroll
   for (int t = 0; t < T; ++t) ad1.v[t] = dtanh(tp.a1.v[t]) * ad1.v[t];
   // gdot1 = qdot1*(1-a1^2) + q1*(-2 a1 adot1) and gdot2 = w3 (-2 a2 (1-a2^2) zdot2): both carry a factor -2, so the
@@ -851,12 +888,12 @@ DEV void h1_bwd_operands(const float* L, Lane ln, const float (&obar)[16], f16x8
 // one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations.
 // MM_F16X2: the HID -> 16 output layer runs as 3 x T/2 v_mfma_f32_16x16x32_f16 (three independent chains) on the
 // hi/lo split of the hidden activations instead of 2T dependent-pair f32 MFMAs of 32 cycles each.
-template <int HID, int MM = MM_F32>
+template <int HID, int MM = MM_F32, int SITE = kInHNet1>
 DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, float (&out)[16]) {
   using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(h, L + Y::oC1, ln);
-  in_layer<T>(h, L + Y::oV1f, ln, sel4(x, ln.q));
+  in_layer_mm<T, MM, SITE>(h, L, Y::oV1f, Y::oV1h, ln, x);
   tanh_act_pre<T>(h);
   Act<1> o;
   if (Y::HF) {
@@ -1005,7 +1042,7 @@ struct PhnnModel {
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       hnet_layer1<HID, MM>(L + oH, ln, x, tp.a1);
     } else {
-      dH = hnet_grad<HID, false, MM>(L + oH, ln, x, tp, Hdummy);
+      dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, x, tp, Hdummy);
     }
     if (WG) {
       store_rec<T>(rec, ln, tp.a2);
@@ -1016,7 +1053,7 @@ struct PhnnModel {
     {
       Act<T> hR;
       float rf[16];
-      h1_fwd<HID, MM>(L + oR, scr, ln, x, hR, rf);
+      h1_fwd<HID, MM, kInHNet1Adj>(L + oR, scr, ln, x, hR, rf);
 #pragma unroll
       for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -1060,7 +1097,7 @@ struct PhnnModel {
     } else {
       Act<T> hG;
       float gf[16], gbar[16];
-      h1_fwd<HID, MM>(L + oGn, scr, ln, x, hG, gf);
+      h1_fwd<HID, MM, kInHNet1Adj>(L + oGn, scr, ln, x, hG, gf);
 #pragma unroll
       for (int k = 0; k < 16; ++k) gbar[k] = 0.f;
 #pragma unroll
@@ -1286,7 +1323,7 @@ struct CanonModel {
         dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
         hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
       } else {
-        dH = hnet_grad<HID, false, MM>(L + oH, ln, z, tp, Hdummy);
+        dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, z, tp, Hdummy);
       }
       const float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
       const float dp0 = (-dH[0] - Rd2 * dH[2]) + Base_Gu(L, 2, u);
@@ -1332,7 +1369,7 @@ struct CanonModel {
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
     } else {
-      dH = hnet_grad<HID, false, MM>(L + oH, ln, z, tp, Hdummy);
+      dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, z, tp, Hdummy);
     }
     float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
     float dp0 = (-dH[0] - Rd2 * dH[2]) + Base_Gu(L, 2, u);
@@ -1471,12 +1508,12 @@ struct HTapeW {
   ActW a1, a2, q1;
 };
 
-template <class PreBarrier>
+template <int SITE = kInHFwd, class PreBarrier>
 DEV f32x4 hnet_grad_w(const float* L, Lane ln, f32x4 z, HTapeW& tp, PreBarrier pre_barrier) {
   using Y = LayH2<128, MM_F16X2>;
   const int t0 = 2 * ln.w;
   load_vec<2>(tp.a1, L + Y::oB1 + 16 * t0, ln);
-  in_layer<2>(tp.a1, L + Y::oW1f + 64 * t0, ln, sel4(z, ln.q));
+  in_layer_mm<2, MM_F16X2, SITE>(tp.a1, L, Y::oW1f, Y::oW1h, ln, z, t0);
   tanh_pre_w(tp.a1);
   {
     Split2<2> sp;
@@ -1538,7 +1575,7 @@ DEV f32x4 hnet_hvp_w(const float* L, Lane ln, HTapeW& tp, f32x4 v, float& scale)
   const float unscale = __builtin_ldexpf(1.0f, e);
   ActW ad1, w;
   zero_act<2>(ad1);
-  in_layer<2>(ad1, L + Y::oW1f + 64 * t0, ln, sel4(v, ln.q));
+  in_layer_mm<2, MM_F16X2, kInHHvp>(ad1, L, Y::oW1f, Y::oW1h, ln, v, t0);
 #pragma unroll
   for (int t = 0; t < 2; ++t) ad1.v[t] = dtanh(tp.a1.v[t]) * ad1.v[t];
 #pragma unroll
@@ -1593,10 +1630,11 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
   using YR = LayH1<128, MM_F16X2>;
 
   // R_net hidden layer on the own tiles; fragments to region 2
+  template <int SITE = kInHNet1>
   DEV static void rnet_layer1(const float* L, Lane ln, f32x4 x, ActW& hR) {
     const int t0 = 2 * ln.w;
     load_vec<2>(hR, L + oR + YR::oC1 + 16 * t0, ln);
-    in_layer<2>(hR, L + oR + YR::oV1f + 64 * t0, ln, sel4(x, ln.q));
+    in_layer_mm<2, MM_F16X2, SITE>(hR, L + oR, YR::oV1f, YR::oV1h, ln, x, t0);
     tanh_pre_w(hR);
     Split2<2> sp;
     split_act_h<2>(hR, sp);
@@ -1649,13 +1687,13 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       using Y = LayH2<128, MM_F16X2>;
       load_vec<2>(tp.a1, L + oH + Y::oB1 + 16 * t0, ln);
-      in_layer<2>(tp.a1, L + oH + Y::oW1f + 64 * t0, ln, sel4(x, ln.q));
+      in_layer_mm<2, MM_F16X2, kInHRecomp>(tp.a1, L + oH, Y::oW1f, Y::oW1h, ln, x, t0);
       tanh_pre_w(tp.a1);
-      rnet_layer1(L, ln, x, hR);
+      rnet_layer1<kInHNet1Adj>(L, ln, x, hR);
       __syncthreads();
       rnet_out(L, scr, ln, rf);
     } else {
-      f32x4 P = hnet_grad_w(L + oH, ln, x, tp, [&]() { rnet_layer1(L, ln, x, hR); });
+      f32x4 P = hnet_grad_w<kInHRecomp>(L + oH, ln, x, tp, [&]() { rnet_layer1<kInHNet1Adj>(L, ln, x, hR); });
       xch_put_partial(ln.xch + kXP0, ln, P);
       rnet_out(L, scr, ln, rf);
       __syncthreads();
@@ -1787,10 +1825,10 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       using Y = LayH2<128, MM_F16X2>;
       load_vec<2>(tp.a1, L + oH + Y::oB1 + 16 * t0, ln);
-      in_layer<2>(tp.a1, L + oH + Y::oW1f + 64 * t0, ln, sel4(z, ln.q));
+      in_layer_mm<2, MM_F16X2, kInHRecomp>(tp.a1, L + oH, Y::oW1f, Y::oW1h, ln, z, t0);
       tanh_pre_w(tp.a1);
     } else {
-      f32x4 P = hnet_grad_w(L + oH, ln, z, tp, []() {});
+      f32x4 P = hnet_grad_w<kInHRecomp>(L + oH, ln, z, tp, []() {});
       xch_put_partial(ln.xch + kXP0, ln, P);
       __syncthreads();
       dH = xch_sum_partials(ln.xch + kXP0, ln);

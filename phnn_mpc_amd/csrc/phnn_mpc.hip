@@ -238,6 +238,23 @@ void pack_in_frag(float* dst, const float* W, int nin) {  // W (HID, nin) -> [T]
       dst[nt * 64 + lane] = q < nin ? W[(size_t)(16 * nt + i) * nin + q] : 0.f;
     }
 }
+// f16x2 input layer (in_layer_h): [T][64] lanes x 8 halves; lane (i,0): hi(W[u][0..3]) twice, lane (i,1): lo(W[u][0..3])
+// twice, lanes q >= 2: zeros
+template <int HID>
+void pack_in_frag_h(float* dstf, const float* W, int nin) {
+  _Float16* dst = reinterpret_cast<_Float16*>(dstf);
+  for (int nt = 0; nt < HID / 16; ++nt)
+    for (int lane = 0; lane < 64; ++lane) {
+      int i = lane & 15, q = lane >> 4;
+      for (int j = 0; j < 8; ++j) {
+        int c = j & 3;
+        float x = (q < 2 && c < nin) ? W[(size_t)(16 * nt + i) * nin + c] : 0.f;
+        _Float16 h = (_Float16)x;
+        _Float16 l = (_Float16)(x - (float)h);
+        dst[(size_t)(nt * 64 + lane) * 8 + j] = q == 0 ? h : (q == 1 ? l : (_Float16)0.f);
+      }
+    }
+}
 template <int HID>
 void pack_in_frag_T(float* dst, const float* W, int nout) {  // W (nout, HID): frag of W^T (HID, nout)
   for (int nt = 0; nt < HID / 16; ++nt)
@@ -336,6 +353,7 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   else pack_rows(dst + Y::oW2, W2s.data(), HID, HID, Y::LD);
   S *= k1;
   pack_in_frag<HID>(dst + Y::oW1f, W1s.data(), nin);
+  if (MM == MM_F16X2) pack_in_frag_h<HID>(dst + Y::oW1h, W1s.data(), nin);
   for (int k = 0; k < HID; ++k) dst[Y::oB1 + k] = b1[k] * k1;
   memcpy(dst + Y::oW3, W3, sizeof(float) * HID);
   pack_cols_as_rows(dst + Y::oW1T, W1, HID, nin, Y::LR);
@@ -406,6 +424,7 @@ const float* pack_h1(float* dst, const float* p, int nin, int nout) {  // R_net 
   std::vector<float> V1s((size_t)HID * nin);
   for (size_t k = 0; k < V1s.size(); ++k) V1s[k] = V1[k] * k1;
   pack_in_frag<HID>(dst + Y::oV1f, V1s.data(), nin);
+  if (Y::HF) pack_in_frag_h<HID>(dst + Y::oV1h, V1s.data(), nin);
   for (int k = 0; k < HID; ++k) dst[Y::oC1 + k] = c1[k] * k1;
   memcpy(dst + Y::oC2, c2, sizeof(float) * nout);
   pack_cols_as_rows(dst + Y::oV1T, V1, HID, nin, Y::LR);
