@@ -1024,7 +1024,10 @@ struct PhnnModel {
   }
 
   // weight-gradient record of one evaluation (WRec): a2, q1, ad2, qd, hbR [, hbG] + the per-rollout small vectors
-  static constexpr int NBIG = FIXG ? 5 : 6;
+  // hbR / hbG are part of the record only when the output layers are not f16x2 images: with those the reduction
+  // recomputes them from rbar / gbar and V2 (four f32 MFMAs per record and wave instead of 1 KB of record per tile)
+  static constexpr bool RECHB = !LayH1<HID, MM>::HF;
+  static constexpr int NBIG = 4 + (RECHB ? (FIXG ? 1 : 2) : 0);
   using Rec = WRec<T, NBIG>;
 
   // xbar = (df/dx)^T lam, ubar = (df/du)^T lam at (x,u); recomputes the forward tape it needs.
@@ -1081,7 +1084,7 @@ struct PhnnModel {
           float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
           rbar[i * N + j] = (sij + sji) * 0.5f;
         }
-      xb += h1_bwd<HID, MM, WG>(L + oR, ln, hR, rbar, WG ? rec + 4 * Rec::VEC : nullptr);
+      xb += h1_bwd<HID, MM, WG && RECHB>(L + oR, ln, hR, rbar, WG && RECHB ? rec + 4 * Rec::VEC : nullptr);
       if (WG && ln.q == 0) {
         f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
 #pragma unroll
@@ -1107,7 +1110,7 @@ struct PhnnModel {
           ubar[k] = __builtin_fmaf(gf[i * MI + k], lam[i], ubar[k]);
           gbar[i * MI + k] = lam[i] * u[k];
         }
-      xb += h1_bwd<HID, MM, WG>(L + oGn, ln, hG, gbar, WG ? rec + 5 * Rec::VEC : nullptr);
+      xb += h1_bwd<HID, MM, WG && RECHB>(L + oGn, ln, hG, gbar, WG && RECHB ? rec + 5 * Rec::VEC : nullptr);
     }
     // v = A^T lam, A = Jeff - S S^T
     f32x4 v = splat4(0.f);
@@ -2489,16 +2492,16 @@ struct BlobOf<CanonModel<HID, MM, MI, MASS_CARTPOLE>> {
 };
 
 template <class M>
-struct IsPhnn { static constexpr bool value = false; };
+struct IsPhnn { static constexpr bool value = false, gnet = false; };
 template <int N, int HID, bool FIXG, int MM, int MI>
-struct IsPhnn<PhnnModel<N, HID, FIXG, MM, MI>> { static constexpr bool value = true; };
+struct IsPhnn<PhnnModel<N, HID, FIXG, MM, MI>> { static constexpr bool value = true, gnet = !FIXG; };
 
 // geometry of k_wgrad_reduce (shared with the host's LDS size).  Staged constants: only the small vectors of each net
 // (H_net: W1 fragments, b1 ... b3; R_net / G_net: V1 fragments, c1, c2, scale).  Exchange buffer (floats).
 template <class M>
 struct WgGeom {
   static constexpr bool PHNN = IsPhnn<M>::value;
-  static constexpr bool GNET = PHNN && M::Rec::oSmall / M::Rec::VEC == 6;
+  static constexpr bool GNET = IsPhnn<M>::gnet;
   using YH = LayH2<M::HID, M::MM>;
   using Y1 = LayH1<M::HID, M::MM>;
   static constexpr int H0 = YH::oW1f, HN = YH::SIZE - YH::oW1f;          // staged range of the H_net image
@@ -2520,6 +2523,20 @@ DEV void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) 
   l = pk_bf16(t0, t1);
 }
 
+// A fragments of V2^T for the reduction's recomputation of hb (f16x2 images only): lane (i,q) of wave w gets
+// V2[o = 4q + s][unit 16w + i], s = 0..3, rebuilt from the hi/lo halves of the transposed image (exact to 2^-22).
+template <int HID, int MM>
+DEV f32x4 v2_frag(const float* img_net, int w, Lane ln) {
+  using Y = LayH1<HID, MM>;
+  const _Float16* bw = reinterpret_cast<const _Float16*>(img_net + Y::oV2T);
+  const int at = (16 * w + ln.i) * 16 + 4 * ln.q;
+  const float inv = img_net[Y::oSc];
+  f32x4 v;
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) v[s2] = ((float)bw[at + s2] + (float)bw[Y::BPART / 2 + at + s2]) * inv;
+  return v;
+}
+
 // one-hidden-layer net (R_net / G_net) part of a record, for the units of this lane: the vector-shaped sums.  (The
 // output layer's matrix-shaped gradient V2bar = sum obar (x) h goes through the MFMA path with W2bar.)
 template <int N, int HID, int MM, int NOUT>
@@ -2531,10 +2548,19 @@ struct H1Acc {
 
   // hidden activation of this lane's 4 units (recomputed from x); accumulates c1bar, V1bar, c2bar.  ov = the output
   // cotangents 4q .. 4q+3 of this lane's rollout (the values that also go to the exchange as A operand rows).
-  DEV f32x4 add(const float* Lh1, int w, Lane ln, f32x4 x, f32x4 hb, f32x4 ov) {
+  // hb = (V2^T obar) (1 - h^2) of these units: from the record (RECHB models), else recomputed -- v2 = this lane's
+  // A fragments of V2^T (v2[s] = V2[o = 4q + s][unit 16w + i], see v2_frag), B = ov: k-step s, k-slot q <-> o = 4q + s.
+  template <bool RECOMPUTE>
+  DEV f32x4 add(const float* Lh1, int w, Lane ln, f32x4 x, f32x4 hb, f32x4 ov, f32x4 v2) {
     using Y = LayH1<HID, MM>;
     f32x4 c = *reinterpret_cast<const f32x4*>(Lh1 + Y::oC1 + 16 * w + 4 * ln.q);
     f32x4 h = tanh4_model<HID / 16>(mfma(Lh1[Y::oV1f + w * 64 + ln.lane], sel4(x, ln.q), c));
+    if constexpr (RECOMPUTE) {
+      f32x4 d = splat4(0.f);
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) d = mfma(v2[s2], ov[s2], d);
+      hb = d * dtanh(h);
+    }
     c1 += hb;
 #pragma unroll
     for (int k = 0; k < N; ++k) V1[k] += hb * x[k];
@@ -2636,6 +2662,12 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   const f32x4 b1v = *reinterpret_cast<const f32x4*>(L + Y::oB1 + 16 * w + 4 * ln.q);
   const f32x4 w3v = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * w + 4 * ln.q);
   const float w1f = L[Y::oW1f + w * 64 + ln.lane];
+  constexpr bool HBREC = PHNN && !LayH1<HID, MM>::HF;  // hbR / hbG come with the record; else they are recomputed
+  f32x4 v2R = splat4(0.f), v2G = splat4(0.f);
+  if constexpr (PHNN && !HBREC) {
+    v2R = v2_frag<HID, MM>(p.img + M::oR, w, ln);
+    if constexpr (GNET) v2G = v2_frag<HID, MM>(p.img + M::oGn, w, ln);
+  }
 
   f32x4 accW2[T];
 #pragma unroll
@@ -2692,7 +2724,7 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
       // (every wave writes the same values to XO: identical stores, no branch)
       f32x4 gv = splat4(0.f);
       const f32x4 rv = (4 * ln.q < N * N) ? cur.rv : splat4(0.f);
-      hR = accR.add(LR, w, ln, x, cur.big[4], rv);
+      hR = accR.template add<!HBREC>(LR, w, ln, x, HBREC ? cur.big[NB - (GNET ? 2 : 1)] : splat4(0.f), rv, v2R);
 #pragma unroll
       for (int e = 0; e < 4; ++e) XO[(4 * ln.q + e) * LDO + p16] = rv[e];
       if constexpr (GNET) {
@@ -2702,7 +2734,7 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
           for (int i = 0; i < N; ++i)
 #pragma unroll
             for (int k = 0; k < M::MI; ++k) gv[e] = (4 * ln.q + e == i * M::MI + k) ? lam[i] * uu[k] : gv[e];
-        hG = accG.add(LG, w, ln, x, cur.big[5], gv);
+        hG = accG.template add<!HBREC>(LG, w, ln, x, HBREC ? cur.big[NB - 1] : splat4(0.f), gv, v2G);
 #pragma unroll
         for (int e = 0; e < 4; ++e) XO[(16 + 4 * ln.q + e) * LDO + p16] = gv[e];
       }
