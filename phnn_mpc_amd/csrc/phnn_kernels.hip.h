@@ -1047,7 +1047,7 @@ struct PhnnModel {
     } else {
       dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, x, tp, Hdummy);
     }
-    if (WG) {
+    if (WG && !ST) {  // with the tapes of K1 the reduction reads a2, q1 from there (their record slots stay unwritten)
       store_rec<T>(rec, ln, tp.a2);
       store_rec<T>(rec + Rec::VEC, ln, tp.q1);
     }
@@ -1388,8 +1388,10 @@ struct CanonModel {
     f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
     ubar = Base_Gt(L, dpb0, dpb1);
     if (WG) {
-      store_rec<T>(rec, ln, tp.a2);
-      store_rec<T>(rec + Rec::VEC, ln, tp.q1);
+      if (!ST) {
+        store_rec<T>(rec, ln, tp.a2);
+        store_rec<T>(rec + Rec::VEC, ln, tp.q1);
+      }
       if (ln.q == 0) {
         f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
         sm[0] = z;
@@ -2316,7 +2318,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
         if (s != 3) in = in + (s == 2 ? p.dt : p.half_dt) * ybn;
         if (s == 0 && db) in = in + load_state<N>(db + (long long)t * N) * live;
         f32x4 yb;
-        if constexpr (WG) M::template vjp<false, true>(L, scr, ln, y, us, in, yb, ub, nullptr, rec + s * M::Rec::SIZE);
+        if constexpr (WG) M::template vjp<STASH, true>(L, scr, ln, y, us, in, yb, ub, STASH ? sl + s * SLOT : nullptr, rec + s * M::Rec::SIZE);
         else M::template vjp<STASH>(L, scr, ln, y, us, in, yb, ub, STASH ? sl + s * SLOT : nullptr);
         utot = s == 3 ? ub : utot + ub;
         ybn = yb;
@@ -2437,6 +2439,8 @@ struct WgradParams {
   long long n_rec;
   float* slab;        // [gridDim.x][PP]
   int PP;
+  const float* tapes;  // TAPES kernels: K1's stash, slot of record r at tapes + r * tape_stride (a2, q1 lead the slot)
+  int tape_stride;
 };
 
 template <int T>
@@ -2596,10 +2600,12 @@ template <int NB>
 struct RecSlice {
   f32x4 big[NB], x, v, lam, dH, rv, uu;
   float Hbar;
-  DEV void load(const float* R, int vec4, int oSmall, int w, Lane ln) {
+  // tape != null: a2, q1 (big vectors 0, 1) come from K1's stash slot of this record
+  DEV void load(const float* R, int vec4, int oSmall, int w, Lane ln, const float* tape = nullptr) {
     const f32x4* bg = reinterpret_cast<const f32x4*>(R) + w * 64 + ln.lane;
+    const f32x4* tg = reinterpret_cast<const f32x4*>(tape) + w * 64 + ln.lane;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) big[k] = bg[k * vec4];
+    for (int k = 0; k < NB; ++k) big[k] = (tape && k < 2) ? tg[k * vec4] : bg[k * vec4];
     const f32x4* s4 = reinterpret_cast<const f32x4*>(R + oSmall + ln.i * kRecSmall);
     x = s4[0];
     v = s4[1];
@@ -2611,10 +2617,7 @@ struct RecSlice {
   }
 };
 
-#ifndef PHNN_RED_ORDER
-#define PHNN_RED_ORDER 0
-#endif
-template <class M>
+template <class M, bool TAPES = false>
 __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int N = M::N, HID = M::HID, T = M::T, MM = M::MM;
@@ -2824,42 +2827,22 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
   };
   const long long G = gridDim.x, last = p.n_rec - 1;
   auto slice_of = [&](long long r) { return p.rec + (r < last ? r : last) * Rec::SIZE; };  // clamped: a prefetch past the end re-reads the last record
+  auto tape_of = [&](long long r) { return TAPES ? p.tapes + (r < last ? r : last) * (long long)p.tape_stride : nullptr; };
   if ((long long)blockIdx.x < p.n_rec) {
     long long r = blockIdx.x;
     RecSlice<NB> cur, nxt;
-    cur.load(slice_of(r), Rec::VEC / 4, Rec::oSmall, w, ln);
-    nxt.load(slice_of(r + G), Rec::VEC / 4, Rec::oSmall, w, ln);
+    cur.load(slice_of(r), Rec::VEC / 4, Rec::oSmall, w, ln, tape_of(r));
+    nxt.load(slice_of(r + G), Rec::VEC / 4, Rec::oSmall, w, ln, tape_of(r + G));
     stage(cur, 0);
     __syncthreads();
     int buf = 0;
     for (r += G; r < p.n_rec; r += G, buf ^= 1) {
       cur = nxt;
-      nxt.load(slice_of(r + G), Rec::VEC / 4, Rec::oSmall, w, ln);
-      // the two waves of a SIMD (w and w + T/2) run the two halves in opposite order: one streams MFMAs while the
-      // other does vector work
-#if PHNN_RED_ORDER == 0
+      nxt.load(slice_of(r + G), Rec::VEC / 4, Rec::oSmall, w, ln, tape_of(r + G));
+      // (measured and not kept: stage before gemm +4 %; the two waves of a SIMD in opposite orders: spills, +50 %;
+      // sched_group_barrier MFMA / VALU interleaving: no change)
       gemm(buf);
       stage(cur, buf ^ 1);
-#elif PHNN_RED_ORDER == 3
-      gemm(buf);
-      stage(cur, buf ^ 1);
-#pragma unroll
-      for (int k = 0; k < 6 * T + 8; ++k) {  // one MFMA per PHNN_RED_VPM vector instructions
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, PHNN_RED_VPM, 0);
-      }
-#elif PHNN_RED_ORDER == 1
-      stage(cur, buf ^ 1);
-      gemm(buf);
-#else
-      if (w < T / 2) {
-        gemm(buf);
-        stage(cur, buf ^ 1);
-      } else {
-        stage(cur, buf ^ 1);
-        gemm(buf);
-      }
-#endif
       __syncthreads();
     }
     gemm(buf);

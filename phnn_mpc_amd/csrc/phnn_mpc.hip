@@ -820,7 +820,7 @@ int check_cost(phnn_handle* h, const phnn_cost* c) {
 
 extern "C" {
 
-int phnn_version(void) { return 200; }
+int phnn_version(void) { return 210; }
 
 const char* phnn_variant_name(const phnn_handle* h) { return h ? h->ks.name : ""; }
 
@@ -913,6 +913,9 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
     if (e == hipSuccess) e = allow_big_lds(h->wg.grad[1]);
     if (e == hipSuccess) e = allow_big_lds(h->wg.mvjp);
     if (e == hipSuccess) e = allow_big_lds(h->wg.reduce);
+    if (e == hipSuccess) e = allow_big_lds(h->wg.grad_t[0]);
+    if (e == hipSuccess) e = allow_big_lds(h->wg.grad_t[1]);
+    if (e == hipSuccess) e = allow_big_lds(h->wg.reduce_t);
   }
   if (h->has_split) {
     if (e == hipSuccess) e = allow_big_lds(h->sp.fwd[0]);
@@ -1093,19 +1096,30 @@ static int wgrad_rows(const phnn_handle* h, long long n_rec) {
   return (int)(rows < 1 ? 1 : rows);
 }
 
+// workspace layout (floats): [records n_rec x rec_floats][slab rows x blob_floats, rounded up to 64][tapes n_rec x
+// tape_floats (rollout mode only: K1's stash when phnn_rollout_trajectory_ws filled it)]
+static size_t wgrad_tape_offset(const phnn_handle* h, long long n_rec) {
+  size_t o = (size_t)n_rec * (size_t)h->wg.rec_floats + (size_t)wgrad_rows(h, n_rec) * (size_t)h->wg.blob_floats;
+  return (o + 63) / 64 * 64;
+}
 size_t phnn_wgrad_workspace_bytes(const phnn_handle* h, int64_t B, int32_t H, int32_t integrator) {
   if (!h || !h->has_wgrad || B <= 0) return 0;
+  if (H > 0 && integrator != PHNN_INTEG_EULER && integrator != PHNN_INTEG_RK4) return 0;
   long long n_rec = wgrad_records(B, H, integrator);
-  return sizeof(float) * ((size_t)n_rec * (size_t)h->wg.rec_floats + (size_t)wgrad_rows(h, n_rec) * (size_t)h->wg.blob_floats);
+  size_t floats = wgrad_tape_offset(h, n_rec);
+  if (H > 0) floats += (size_t)n_rec * (size_t)h->wg.tape_floats[integrator];
+  return sizeof(float) * floats;
 }
 
 static int wgrad_reduce(phnn_handle* h, void* workspace_dev, long long n_rec, float* grad_theta_dev, int accumulate,
-                        hipStream_t st) {
+                        hipStream_t st, int tape_floats = 0) {
   float* rec = (float*)workspace_dev;
   float* slab = rec + (size_t)n_rec * (size_t)h->wg.rec_floats;
   const int rows = wgrad_rows(h, n_rec);
-  WgradParams wp{h->d_img, rec, n_rec, slab, h->wg.blob_floats};
-  hipLaunchKernelGGL(h->wg.reduce, dim3((unsigned)rows), dim3(64 * h->wg.reduce_waves), (size_t)h->wg.reduce_lds_bytes, st, wp);
+  WgradParams wp{h->d_img, rec, n_rec, slab, h->wg.blob_floats, tape_floats ? rec + wgrad_tape_offset(h, n_rec) : nullptr,
+                 tape_floats};
+  hipLaunchKernelGGL(tape_floats ? h->wg.reduce_t : h->wg.reduce, dim3((unsigned)rows), dim3(64 * h->wg.reduce_waves),
+                     (size_t)h->wg.reduce_lds_bytes, st, wp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, e, "wgrad reduce launch");
   e = phnn_wgrad_finish(slab, rows, h->wg.blob_floats, h->d_unpad, h->n_params, grad_theta_dev, accumulate, st);
@@ -1115,7 +1129,15 @@ static int wgrad_reduce(phnn_handle* h, void* workspace_dev, long long n_rec, fl
 
 int phnn_rollout_trajectory(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
                             int32_t integrator, float dt, float* traj_dev, float* dx_dev, void* stream) {
+  return phnn_rollout_trajectory_ws(h, x0_dev, u_dev, B, H, integrator, dt, traj_dev, dx_dev, nullptr, stream);
+}
+
+int phnn_rollout_trajectory_ws(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H,
+                               int32_t integrator, float dt, float* traj_dev, float* dx_dev, void* wgrad_workspace_dev,
+                               void* stream) {
   if (!h) return PHNN_ERR_INVALID_ARG;
+  if (wgrad_workspace_dev && !h->has_wgrad)
+    return fail(h, PHNN_ERR_UNSUPPORTED, "no weight-gradient kernels for this model variant: pass a NULL workspace");
   phnn_cost neutral;
   memset(&neutral, 0, sizeof neutral);
   RollParams p;
@@ -1127,15 +1149,20 @@ int phnn_rollout_trajectory(phnn_handle* h, const float* x0_dev, const float* u_
   p.dx_out = dx_dev;
   p.no_cost = 1;
   const long long tiles = (B + kTileB - 1) / kTileB;
-  if (use_split(h, tiles)) return launch_split(h, h->sp.fwd[integrator], p, tiles, (hipStream_t)stream);
-  return launch(h, h->ks.fwd[integrator], p, tiles, false, (hipStream_t)stream);
+  const bool tapes = wgrad_workspace_dev != nullptr;
+  if (tapes) p.stash = (float*)wgrad_workspace_dev + wgrad_tape_offset(h, wgrad_records(B, H, integrator));
+  if (use_split(h, tiles))
+    return launch_split(h, tapes ? h->sp.fwd_stash[integrator] : h->sp.fwd[integrator], p, tiles, (hipStream_t)stream);
+  return launch(h, tapes ? h->ks.fwd_stash[integrator] : h->ks.fwd[integrator], p, tiles, false, (hipStream_t)stream);
 }
 
 int phnn_rollout_wgrad(phnn_handle* h, const float* x0_dev, const float* u_dev, int64_t B, int32_t H, int32_t integrator,
                        float dt, const float* traj_dev, const float* traj_bar_dev, const float* dx_bar_dev,
-                       void* workspace_dev, float* grad_theta_dev, int32_t accumulate, float* grad_u_dev,
+                       void* workspace_dev, float* grad_theta_dev, int32_t flags, float* grad_u_dev,
                        float* grad_x0_dev, void* stream) {
   if (!h) return PHNN_ERR_INVALID_ARG;
+  const int accumulate = (flags & PHNN_WGRAD_ACCUMULATE) != 0;
+  const bool tapes = (flags & PHNN_WGRAD_TAPES) != 0;
   if (!h->has_wgrad)
     return fail(h, PHNN_ERR_UNSUPPORTED, "no weight-gradient kernels for this model variant (pHNN and canonical pHNN have them)");
   phnn_cost neutral;
@@ -1160,8 +1187,11 @@ int phnn_rollout_wgrad(phnn_handle* h, const float* x0_dev, const float* u_dev, 
   p.grad_x0 = grad_x0_dev;
   p.no_cost = 1;
   p.wrec = (float*)workspace_dev;
-  if (int rc = launch(h, h->wg.grad[integrator], p, (B + kTileB - 1) / kTileB, false, st)) return rc;
-  return wgrad_reduce(h, workspace_dev, wgrad_records(B, H, integrator), grad_theta_dev, accumulate, st);
+  const long long n_rec = wgrad_records(B, H, integrator);
+  if (tapes) p.stash = (float*)workspace_dev + wgrad_tape_offset(h, n_rec);
+  if (int rc = launch(h, tapes ? h->wg.grad_t[integrator] : h->wg.grad[integrator], p, (B + kTileB - 1) / kTileB, false, st))
+    return rc;
+  return wgrad_reduce(h, workspace_dev, n_rec, grad_theta_dev, accumulate, st, tapes ? h->wg.tape_floats[integrator] : 0);
 }
 
 int phnn_model_wgrad(phnn_handle* h, const float* x_dev, const float* u_dev, const float* lam_dev, const float* Hbar_dev,

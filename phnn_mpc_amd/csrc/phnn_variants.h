@@ -94,8 +94,11 @@ bool phnn_split_kernels(int variant, SplitSet* g);  // false: no split-tile kern
 // variants: the adjoint kernels built with the record flag (recompute mode) and the record reduction.
 struct WgradSet {
   void (*grad[2])(RollParams);  // K2 + records: Euler, RK4
+  void (*grad_t[2])(RollParams);  // the same fed by K1's tapes (a2, q1 stay out of the record)
   void (*mvjp)(PointParams);    // single-evaluation VJP + record
   void (*reduce)(WgradParams);
+  void (*reduce_t)(WgradParams);  // reads a2, q1 from the tapes
+  int tape_floats[2];  // floats per record slot of the tapes: Euler, RK4
   int rec_floats;     // floats per record
   int blob_floats;    // floats per slab row = size of the (width-padded) weight blob
   int reduce_waves;   // waves per workgroup of the reduce kernel (= hidden width / 16)

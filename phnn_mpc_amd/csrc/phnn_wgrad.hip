@@ -12,12 +12,16 @@ static WgradSet wgrad_set() {
   WgradSet g;
   g.grad[0] = k_rollout_grad<M, PHNN_INTEG_EULER, false, true>;
   g.grad[1] = k_rollout_grad<M, PHNN_INTEG_RK4, false, true>;
+  g.grad_t[0] = k_rollout_grad<M, PHNN_INTEG_EULER, true, true>;
+  g.grad_t[1] = k_rollout_grad<M, PHNN_INTEG_RK4, true, true>;
   g.mvjp = k_model_vjp<M, true>;
-  g.reduce = k_wgrad_reduce<M>;
+  g.reduce = k_wgrad_reduce<M, false>;
+  g.reduce_t = k_wgrad_reduce<M, true>;
+  g.tape_floats[0] = StashStep<M, PHNN_INTEG_EULER>::FLOATS;
+  g.tape_floats[1] = StashStep<M, PHNN_INTEG_RK4>::SLOT;  // four slots per step = one per record
   g.rec_floats = M::Rec::SIZE;
   g.blob_floats = BlobOf<M>::SIZE;
   g.reduce_waves = M::T;
-  using Y = LayH2<M::HID, M::MM>;
   g.reduce_lds_bytes = (int)sizeof(float) * WgGeom<M>::LDS_FLOATS;
   return g;
 }

@@ -49,6 +49,8 @@ class RolloutEngine:
         self.n, self.m, self.kind = self.desc.n, self.desc.m, self.desc.kind
         self.layout = weights.blob_layout(state_dict, kind=self.kind)  # [(state_dict key, offset, shape)] of the blob
         self._wg_ws = None
+        self._tape_gen, self._tape_token = 0, None  # tapes kept by the last rollout_trajectory(tapes=True), if still valid
+        self.use_tapes = os.environ.get("PHNN_NO_TAPES", "0") != "1"
         if matmul is None:
             matmul = os.environ.get("PHNN_MATMUL", "default")
             force_matmul = force_matmul or "PHNN_MATMUL" in os.environ  # an explicit environment override is a force
@@ -81,6 +83,7 @@ class RolloutEngine:
         if blob.size != self.blob.size:
             raise PhnnError("update_weights: the state_dict describes another architecture")
         self.blob = blob
+        self._tape_token = None  # tapes of the old weights
         rc = self.lib.phnn_update_weights(self.h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, self._stream())
         _check(self.lib, self.h, rc)
 
@@ -227,24 +230,41 @@ class RolloutEngine:
             raise PhnnError("this model variant has no weight-gradient kernels (pHNN and canonical pHNN have them)")
         if self._wg_ws is None or self._wg_ws.numel() < need:
             self._wg_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+            self._tape_token = None  # a new buffer: whatever tapes the old one held are gone
         return self._wg_ws
 
-    def rollout_trajectory(self, x0, u, integrator="euler", dt=0.02, want_dx=False):
-        """Training rollout (no clamp, no cost): x0 (B,n), u (B,H,m) -> traj (B,H+1,n) [, dX (B,H,n) = f(x_t,u_t)]."""
+    def rollout_trajectory(self, x0, u, integrator="euler", dt=0.02, want_dx=False, tapes=False):
+        """Training rollout (no clamp, no cost): x0 (B,n), u (B,H,m) -> traj (B,H+1,n) [, dX (B,H,n) = f(x_t,u_t)].
+        tapes=True (models with weight-gradient kernels): K1 also keeps the tapes of every dynamics evaluation in the
+        weight-gradient workspace; `self.tape_token` then identifies them, and rollout_wgrad(..., tape_token=that)
+        uses them as long as nothing else has touched the workspace or the weights since."""
         x0 = self._t(x0, (-1, self.n))
         B = x0.shape[0]
         u, H = self._controls(u, B)
+        integ = self._integ(integrator)
         traj = torch.empty(B, H + 1, self.n, dtype=torch.float32, device=self.device)
         dX = torch.empty(B, H, self.n, dtype=torch.float32, device=self.device) if want_dx else None
-        rc = self.lib.phnn_rollout_trajectory(self.h, self._p(x0), self._p(u), B, H, self._integ(integrator), float(dt),
-                                              self._p(traj), self._p(dX), self._stream())
+        ws = None
+        if tapes and self.use_tapes and B > 0 and self.has_wgrad:
+            ws = self._wgrad_workspace(B, H, integ)
+            self._tape_gen += 1
+            self._tape_token = (self._tape_gen, B, H, integ, float(dt))
+        rc = self.lib.phnn_rollout_trajectory_ws(self.h, self._p(x0), self._p(u), B, H, integ, float(dt), self._p(traj),
+                                                 self._p(dX), self._p(ws), self._stream())
         _check(self.lib, self.h, rc)
         return (traj, dX) if want_dx else traj
 
+    @property
+    def tape_token(self):
+        """Token of the tapes the weight-gradient workspace currently holds (None: none / invalidated)."""
+        return self._tape_token
+
     def rollout_wgrad(self, x0, u, traj, integrator="euler", dt=0.02, traj_bar=None, dx_bar=None, grad_theta=None,
-                      accumulate=False):
+                      accumulate=False, tape_token=None):
         """Reverse pass of a training rollout: cotangents on the trajectory (B,H+1,n) and on the per-step derivatives
-        (B,H,n) -> (grad_theta (P,) in weight-blob layout, grad_u (B,H,m), grad_x0 (B,n))."""
+        (B,H,n) -> (grad_theta (P,) in weight-blob layout, grad_u (B,H,m), grad_x0 (B,n)).  tape_token: the token
+        rollout_trajectory(tapes=True) left for this very rollout; used only if the tapes are still the current ones
+        (otherwise the adjoint recomputes the forward pass, same results to rounding)."""
         x0 = self._t(x0, (-1, self.n))
         B = x0.shape[0]
         u, H = self._controls(u, B)
@@ -258,8 +278,11 @@ class RolloutEngine:
         gu = torch.empty(B, H, self.m, dtype=torch.float32, device=self.device)
         gx = torch.empty(B, self.n, dtype=torch.float32, device=self.device)
         ws = self._wgrad_workspace(B, H, integ)
+        use_tapes = (tape_token is not None and tape_token == self._tape_token
+                     and tape_token[1:] == (B, H, integ, float(dt)))
+        flags = (_capi.WGRAD_ACCUMULATE if accumulate else 0) | (_capi.WGRAD_TAPES if use_tapes else 0)
         rc = self.lib.phnn_rollout_wgrad(self.h, self._p(x0), self._p(u), B, H, integ, float(dt), self._p(traj),
-                                         self._p(tb), self._p(db), self._p(ws), self._p(grad_theta), int(accumulate),
+                                         self._p(tb), self._p(db), self._p(ws), self._p(grad_theta), flags,
                                          self._p(gu), self._p(gx), self._stream())
         _check(self.lib, self.h, rc)
         return grad_theta, gu, gx
@@ -277,6 +300,7 @@ class RolloutEngine:
         xb = torch.empty_like(x)
         ub = torch.empty(N, self.m, dtype=torch.float32, device=self.device)
         ws = self._wgrad_workspace(N, 0, 0)
+        self._tape_token = None  # point-mode records may reach into the tape region of a rollout-sized workspace
         rc = self.lib.phnn_model_wgrad(self.h, self._p(x), self._p(u), self._p(lam), self._p(hb), N, self._p(ws),
                                        self._p(grad_theta), int(accumulate), self._p(xb), self._p(ub), self._stream())
         _check(self.lib, self.h, rc)

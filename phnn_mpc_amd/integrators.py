@@ -57,7 +57,9 @@ class _RolloutFn(torch.autograd.Function):
         eng = model.engine
         y0d = y0.detach().to(eng.device, torch.float32).contiguous()
         ud = controls.detach().to(eng.device, torch.float32).contiguous()
-        traj, dX = eng.rollout_trajectory(y0d, ud, integrator, dt, want_dx=True)
+        # parameters that need gradients: K1 keeps its tapes for the weight-gradient pass of backward()
+        traj, dX = eng.rollout_trajectory(y0d, ud, integrator, dt, want_dx=True, tapes=bool(keys))
+        ctx.tape_token = eng.tape_token if keys else None
         ctx.model, ctx.dt, ctx.integ, ctx.keys = model, dt, integrator, keys
         ctx.devs = (y0.device, controls.device, params[0].device if params else None)
         ctx.save_for_backward(y0d, ud, traj)
@@ -73,7 +75,8 @@ class _RolloutFn(torch.autograd.Function):
         tb = None if gtraj is None else gtraj.to(eng.device, torch.float32).contiguous()
         db = None if gdx is None else gdx.to(eng.device, torch.float32).contiguous()
         if want_params or (db is not None and eng.has_wgrad):
-            gth, gu, gx = eng.rollout_wgrad(y0d, ud, traj, ctx.integ, ctx.dt, traj_bar=tb, dx_bar=db)
+            gth, gu, gx = eng.rollout_wgrad(y0d, ud, traj, ctx.integ, ctx.dt, traj_bar=tb, dx_bar=db,
+                                            tape_token=ctx.tape_token)
             pg = split_param_grads(eng, gth, ctx.keys, ctx.devs[2]) if want_params else (None,) * nk
             return (gx.to(ctx.devs[0]), gu.to(ctx.devs[1]), None, None, None, None) + pg
         if db is not None and bool((db != 0).any()):

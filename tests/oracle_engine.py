@@ -19,12 +19,14 @@ class OracleEngine:
         self.layout = weights.blob_layout(state_dict, kind=self.m_.desc.kind)
         self.has_wgrad = self.m_.desc.kind != _capi.MODEL_ODEFUNC  # mirrors the product: pHNN and canonical only
 
-    def rollout_trajectory(self, x0, u, integrator="euler", dt=0.02, want_dx=False):
+    tape_token = None  # the CPU stand-in keeps no tapes (the product's K1 -> K2w shortcut)
+
+    def rollout_trajectory(self, x0, u, integrator="euler", dt=0.02, want_dx=False, tapes=False):
         r = self.m_.rollout_wgrad(np.asarray(x0), np.asarray(u), integrator, dt)
         return (self._out(r["traj"]), self._out(r["dX"])) if want_dx else self._out(r["traj"])
 
     def rollout_wgrad(self, x0, u, traj, integrator="euler", dt=0.02, traj_bar=None, dx_bar=None, grad_theta=None,
-                      accumulate=False):
+                      accumulate=False, tape_token=None):
         r = self.m_.rollout_wgrad(np.asarray(x0), np.asarray(u), integrator, dt,
                                   None if traj_bar is None else np.asarray(traj_bar),
                                   None if dx_bar is None else np.asarray(dx_bar))

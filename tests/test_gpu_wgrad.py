@@ -204,6 +204,24 @@ def test_rollout_wgrad_vs_oracle_ragged(torch, name):
         acc = g1.clone()
         eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb, dx_bar=db, grad_theta=acc, accumulate=True)
         assert torch.allclose(acc, 2 * g1, rtol=1e-6, atol=0)
+        # tape mode: K1 keeps its tapes in the workspace, the adjoint and the reduction read them (no recomputation,
+        # a2 / q1 not copied into the records): same gradients to rounding, against the oracle at the stated tolerance
+        traj_t, dX_t = eng.rollout_trajectory(x0, U, integ, dt, want_dx=True, tapes=True)
+        tok = eng.tape_token
+        assert tok is not None and torch.equal(traj_t, traj)
+        gt, gut, gxt = eng.rollout_wgrad(x0, U, traj_t, integ, dt, traj_bar=tb, dx_bar=db, tape_token=tok)
+        check_named({k: npy(v) for k, v in eng.named_grads(gt).items()}, oracle_named(w, ref["grad_theta"]), (name, B, H, integ, "tapes"))
+        assert float((gt - g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+        assert np.abs(npy(gut) - ref["grad_u"]).max() <= TOL * np.abs(ref["grad_u"]).max()
+        assert np.abs(npy(gxt) - ref["grad_x0"]).max() <= TOL * np.abs(ref["grad_x0"]).max()
+        gt2, _, _ = eng.rollout_wgrad(x0, U, traj_t, integ, dt, traj_bar=tb, dx_bar=db, tape_token=tok)
+        assert torch.equal(gt, gt2)  # the tapes survive their own backward; bitwise repeatable
+        # a stale token (another tape-writing forward, a point-mode call or a weight update since) falls back to recomputation
+        eng.rollout_trajectory(x0, U, integ, dt, tapes=True)
+        g_stale, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb, dx_bar=db, tape_token=tok)
+        assert torch.equal(g_stale, g1)
+        eng.update_weights(w)
+        assert eng.tape_token is None
     # only one of the two cotangents
     g_t, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb)
     g_d, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, dx_bar=db)

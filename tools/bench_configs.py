@@ -134,16 +134,18 @@ def main():
         x0, U = [torch.tensor(a, device=dev) for a in inputs(n, B, H, 5.0)]
         tb = torch.randn(B, H + 1, n, device=dev)
 
-        def train_pass():
-            traj = eng.rollout_trajectory(x0, U, "euler", dt)
-            eng.rollout_wgrad(x0, U, traj, "euler", dt, traj_bar=tb)
+        def train_pass(tapes=True):  # what _RolloutFn does: K1 keeps its tapes for the adjoint + reduction
+            traj = eng.rollout_trajectory(x0, U, "euler", dt, tapes=tapes)
+            eng.rollout_wgrad(x0, U, traj, "euler", dt, traj_bar=tb, tape_token=eng.tape_token)
 
         t = timed(train_pass, reps=5, warm=2)
+        t_rc = timed(lambda: train_pass(False), reps=5, warm=2)
         # algorithmic FLOPs per rollout-step: forward 73.0 k + VJP 74.2 k + the parameter outer products:
         # 2 x 2 x 128 x 128 (W2) + 2 x 16 x 128 (V2) + small = 69.9 k
         out.append({"config": f"f4: {name} training pass (rollout + parameter gradient), euler, H={H}, B={B}",
                     "ms": round(t * 1e3, 3), "rollouts_wgrads_per_s": round(B / t, 1),
-                    "record_bytes_per_rollout_step": eng.lib.phnn_wgrad_workspace_bytes(eng.h, 16, 1, 0) // 16})
+                    "ms_adjoint_recomputes": round(t_rc * 1e3, 3),
+                    "workspace_bytes_per_rollout_step": eng.lib.phnn_wgrad_workspace_bytes(eng.h, 16, 1, 0) // 16})
     for o in out:
         print(json.dumps(o))
 
