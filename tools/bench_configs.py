@@ -136,7 +136,7 @@ def main():
 
         def train_pass(tapes=True):  # what _RolloutFn does: K1 keeps its tapes for the adjoint + reduction
             traj = eng.rollout_trajectory(x0, U, "euler", dt, tapes=tapes)
-            eng.rollout_wgrad(x0, U, traj, "euler", dt, traj_bar=tb, tape_token=eng.tape_token)
+            eng.rollout_wgrad(x0, U, traj, "euler", dt, traj_bar=tb, tape_token=eng.tape_token if tapes else None)
 
         t = timed(train_pass, reps=5, warm=2)
         t_rc = timed(lambda: train_pass(False), reps=5, warm=2)
