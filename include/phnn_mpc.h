@@ -169,8 +169,8 @@ int phnn_rollout_fwd(phnn_handle* h, const float* x0_dev, const float* u_dev, in
 
 /* Optional K1 -> K2 workspace.  With workspace_dev != NULL (at least phnn_workspace_bytes() bytes) K1 also streams
  * the H_net / network activations of every dynamics evaluation to it and K2, given the same pointer, reads them back
- * instead of re-evaluating the forward pass: about half of K2's matrix work for 1 KB per rollout-step of extra HBM
- * traffic each way (cart-pole, Euler).  RK4 keeps four stage slots per step (tape + stage state: 4.1 KB per
+ * instead of re-evaluating the forward pass: about half of K2's matrix work for 1.1 KB per rollout-step of extra HBM
+ * traffic each way (cart-pole, Euler).  RK4 keeps four stage slots per step (tape + stage state: 4.4 KB per
  * rollout-step), so that K2 runs no forward evaluation at all; pass NULL to trade that memory for recomputation.
  * The workspace passed to phnn_rollout_grad / phnn_rollout_vjp must have been filled by phnn_rollout_fwd with the
  * same (x0, u, B, H, cost, integrator, dt). */

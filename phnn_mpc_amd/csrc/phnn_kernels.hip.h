@@ -888,8 +888,32 @@ DEV void h1_bwd_operands(const float* L, Lane ln, const float (&obar)[16], f16x8
 // one-hidden-layer net in(<=4) -> HID -> out(<=16): forward keeps the hidden activations.
 // MM_F16X2: the HID -> 16 output layer runs as 3 x T/2 v_mfma_f32_16x16x32_f16 (three independent chains) on the
 // hi/lo split of the hidden activations instead of 2T dependent-pair f32 MFMAs of 32 cycles each.
+// the 16 outputs of R_net per rollout in the K1 -> K2 tape: lane (i,q) keeps out[4q .. 4q+3] of rollout i (every lane
+// holds all 16 after gather16), one coalesced 1 KB store / load per wave
+DEV void store_rf(float* dst, Lane ln, f32x4 o) {  // o = outputs 4q .. 4q+3 of rollout i, as the output layer leaves them
+  if (ln.w == 0) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst) + ln.i * 4 + ln.q);
+}
+DEV void load_rf(const float* src, Lane ln, float (&rf)[16]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(src) + ln.i * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x4 v = __builtin_nontemporal_load(p + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rf[4 * k + e] = v[e];
+  }
+}
+// hidden layer only (the adjoint with a tape: the outputs come from there)
 template <int HID, int MM = MM_F32, int SITE = kInHNet1>
-DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, float (&out)[16]) {
+DEV void h1_hidden(const float* L, Lane ln, f32x4 x, Act<HID / 16>& h) {
+  using Y = LayH1<HID, MM>;
+  constexpr int T = Y::T;
+  load_vec<T>(h, L + Y::oC1, ln);
+  in_layer_mm<T, MM, SITE>(h, L, Y::oV1f, Y::oV1h, ln, x);
+  tanh_act_pre<T>(h);
+}
+
+template <int HID, int MM = MM_F32, int SITE = kInHNet1>
+DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, float (&out)[16], float* rf_stash = nullptr) {
   using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(h, L + Y::oC1, ln);
@@ -904,6 +928,7 @@ DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, 
     o.v[0] = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
     sq_fwd<1, T>(o, L + Y::oV2, ln, h);
   }
+  if (rf_stash) store_rf(rf_stash, ln, o.v[0]);
   gather16(scr, ln, o.v[0], out);
 }
 
@@ -959,8 +984,10 @@ struct PhnnModel {
   static constexpr int oG = oJ + 16;                               // [16] G_fixed, row-major N x MI
   static constexpr int IMG = oG + 16;
 
-  // floats one wave stashes per step for the adjoint: a2, q1 (T x 256 each) + dH (16 x 4); a1 is recomputed
-  static constexpr int STASH = 2 * T * 256 + 64;
+  // floats one wave stashes per step for the adjoint: a2, q1 (T x 256 each) + dH (16 x 4) + the 16 outputs of R_net
+  // (16 x 16; K2 then needs only R_net's hidden layer); a1 is recomputed
+  static constexpr int oStashRf = 2 * T * 256 + 64;
+  static constexpr int STASH = oStashRf + 256;
 
   // dx = (Jeff - S S^T) dH + G u, with S = sym(R_raw).  stash != null: keep the H_net tape for K2.
   template <bool WANT_H, bool ST = false>
@@ -975,7 +1002,7 @@ struct PhnnModel {
     }
     Act<T> hR;
     float rf[16];
-    h1_fwd<HID, MM>(L + oR, scr, ln, x, hR, rf);
+    h1_fwd<HID, MM>(L + oR, scr, ln, x, hR, rf, ST ? stash + oStashRf : nullptr);
     float G[N * MI];  // G(x) row-major (N, MI): G_fixed buffer or G_net(x).view(n, m)  (src/pHNN.py:86-92)
     if (FIXG) {
 #pragma unroll
@@ -1056,7 +1083,12 @@ struct PhnnModel {
     {
       Act<T> hR;
       float rf[16];
-      h1_fwd<HID, MM, kInHNet1Adj>(L + oR, scr, ln, x, hR, rf);
+      if (ST) {  // R_net's outputs come with the tape: only its hidden layer is re-evaluated
+        load_rf(stash + oStashRf, ln, rf);
+        h1_hidden<HID, MM, kInHNet1Adj>(L + oR, ln, x, hR);
+      } else {
+        h1_fwd<HID, MM, kInHNet1Adj>(L + oR, scr, ln, x, hR, rf);
+      }
 #pragma unroll
       for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -1636,20 +1668,25 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
 
   // R_net hidden layer on the own tiles; fragments to region 2
   template <int SITE = kInHNet1>
-  DEV static void rnet_layer1(const float* L, Lane ln, f32x4 x, ActW& hR) {
+  DEV static void rnet_hidden(const float* L, Lane ln, f32x4 x, ActW& hR) {  // own tiles only, nothing exchanged
     const int t0 = 2 * ln.w;
     load_vec<2>(hR, L + oR + YR::oC1 + 16 * t0, ln);
     in_layer_mm<2, MM_F16X2, SITE>(hR, L + oR, YR::oV1f, YR::oV1h, ln, x, t0);
     tanh_pre_w(hR);
+  }
+  template <int SITE = kInHNet1>
+  DEV static void rnet_layer1(const float* L, Lane ln, f32x4 x, ActW& hR) {
+    rnet_hidden<SITE>(L, ln, x, hR);
     Split2<2> sp;
     split_act_h<2>(hR, sp);
     xch_put(ln.xch + kXR2, ln, sp);
   }
   // R_net outputs from the exchanged fragments (after a barrier): all 16 in every lane
-  DEV static void rnet_out(const float* L, float* scr, Lane ln, float (&rf)[16]) {
+  DEV static void rnet_out(const float* L, float* scr, Lane ln, float (&rf)[16], float* rf_stash = nullptr) {
     Split2<8> all;
     xch_get(ln.xch + kXR2, ln, all);
     f32x4 o = h1_out_hf<128, MM_F16X2>(L + oR, ln, all);
+    if (rf_stash) store_rf(rf_stash, ln, o);  // wave 0 writes (ln.w)
     gather16(scr, ln, o, rf);
   }
 
@@ -1662,7 +1699,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
     f32x4 P = hnet_grad_w(L + oH, ln, x, tp, [&]() { rnet_layer1(L, ln, x, hR); });
     xch_put_partial(ln.xch + kXP0, ln, P);
     float rf[16];
-    rnet_out(L, scr, ln, rf);
+    rnet_out(L, scr, ln, rf, ST ? stash + Base::oStashRf : nullptr);
     if (ST) {
       store_act<2>(stash + 2 * ln.w * 256, ln, tp.a2);
       store_act<2>(stash + T * 256 + 2 * ln.w * 256, ln, tp.q1);
@@ -1694,9 +1731,8 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
       load_vec<2>(tp.a1, L + oH + Y::oB1 + 16 * t0, ln);
       in_layer_mm<2, MM_F16X2, kInHRecomp>(tp.a1, L + oH, Y::oW1f, Y::oW1h, ln, x, t0);
       tanh_pre_w(tp.a1);
-      rnet_layer1<kInHNet1Adj>(L, ln, x, hR);
-      __syncthreads();
-      rnet_out(L, scr, ln, rf);
+      load_rf(stash + Base::oStashRf, ln, rf);  // R_net's outputs come with the tape: no fragment exchange, no barrier
+      rnet_hidden<kInHNet1Adj>(L, ln, x, hR);
     } else {
       f32x4 P = hnet_grad_w<kInHRecomp>(L + oH, ln, x, tp, [&]() { rnet_layer1<kInHNet1Adj>(L, ln, x, hR); });
       xch_put_partial(ln.xch + kXP0, ln, P);
