@@ -1066,10 +1066,13 @@ struct PhnnModel {
     HTape<HID> tp;
     float Hdummy;
     f32x4 dH;
-    if (ST) {  // tape written by K1: the loads fly while a1 is recomputed and the R_net part below runs
+    float rf[16];
+    if (ST) {  // tape written by K1: the loads fly while a1 is recomputed and the R_net part below runs.  Loads return
+      // in issue order (vmcnt): the small vectors the R_net part needs first are requested first, the big ones after
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      load_rf(stash + oStashRf, ln, rf);
       load_act<T>(stash, ln, tp.a2);
       load_act<T>(stash + T * 256, ln, tp.q1);
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       hnet_layer1<HID, MM>(L + oH, ln, x, tp.a1);
     } else {
       dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, x, tp, Hdummy);
@@ -1082,9 +1085,7 @@ struct PhnnModel {
     float S[N][N], Stl[N], StdH[N];
     {
       Act<T> hR;
-      float rf[16];
-      if (ST) {  // R_net's outputs come with the tape: only its hidden layer is re-evaluated
-        load_rf(stash + oStashRf, ln, rf);
+      if (ST) {  // R_net's outputs came with the tape: only its hidden layer is re-evaluated
         h1_hidden<HID, MM, kInHNet1Adj>(L + oR, ln, x, hR);
       } else {
         h1_fwd<HID, MM, kInHNet1Adj>(L + oR, scr, ln, x, hR, rf);
@@ -1353,9 +1354,9 @@ struct CanonModel {
       float Hdummy;
       f32x4 dH;
       if (ST) {
+        dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
         load_act<T>(stash, ln, tp.a2);
         load_act<T>(stash + T * 256, ln, tp.q1);
-        dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
         hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
       } else {
         dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, z, tp, Hdummy);
@@ -1399,9 +1400,9 @@ struct CanonModel {
     float Hdummy;
     f32x4 dH;
     if (ST) {
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
       load_act<T>(stash, ln, tp.a2);
       load_act<T>(stash + T * 256, ln, tp.q1);
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
     } else {
       dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, z, tp, Hdummy);
@@ -1724,14 +1725,15 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
     f32x4 dH;
     float rf[16];
     if (ST) {
+      // small vectors first (vmcnt returns loads in issue order; the R_net part needs them first)
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      load_rf(stash + Base::oStashRf, ln, rf);  // R_net's outputs come with the tape: no fragment exchange, no barrier
       load_act<2>(stash + t0 * 256, ln, tp.a2);
       load_act<2>(stash + T * 256 + t0 * 256, ln, tp.q1);
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       using Y = LayH2<128, MM_F16X2>;
       load_vec<2>(tp.a1, L + oH + Y::oB1 + 16 * t0, ln);
       in_layer_mm<2, MM_F16X2, kInHRecomp>(tp.a1, L + oH, Y::oW1f, Y::oW1h, ln, x, t0);
       tanh_pre_w(tp.a1);
-      load_rf(stash + Base::oStashRf, ln, rf);  // R_net's outputs come with the tape: no fragment exchange, no barrier
       rnet_hidden<kInHNet1Adj>(L, ln, x, hR);
     } else {
       f32x4 P = hnet_grad_w<kInHRecomp>(L + oH, ln, x, tp, [&]() { rnet_layer1<kInHNet1Adj>(L, ln, x, hR); });
@@ -1861,9 +1863,9 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
     HTapeW tp;
     f32x4 dH;
     if (ST) {
+      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
       load_act<2>(stash + t0 * 256, ln, tp.a2);
       load_act<2>(stash + T * 256 + t0 * 256, ln, tp.q1);
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       using Y = LayH2<128, MM_F16X2>;
       load_vec<2>(tp.a1, L + oH + Y::oB1 + 16 * t0, ln);
       in_layer_mm<2, MM_F16X2, kInHRecomp>(tp.a1, L + oH, Y::oW1f, Y::oW1h, ln, z, t0);
@@ -2006,8 +2008,8 @@ struct OdeModel {
     float ubar;
     Tape tp;
     if (ST) {
+      load_act<T>(stash + T * 256, ln, tp.a3);  // the backward sweep meets a3 first
       load_act<T>(stash, ln, tp.a2);
-      load_act<T>(stash + T * 256, ln, tp.a3);
       keep_lds_reads_local();
       layer1(L, ln, x, u, tp.a1);
     } else {
