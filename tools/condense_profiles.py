@@ -13,7 +13,7 @@ dst = os.path.join(ROOT, "profiles")
 def one(pattern):
     m = glob.glob(os.path.join(src, pattern), recursive=True)
     assert m, pattern
-    return m[0]
+    return max(m, key=os.path.getmtime)  # gpurun merges successive collections into the same tree: take the latest
 
 
 shutil.copy(one("trace/**/*kernel_stats.csv"), os.path.join(dst, prefix + "_kernel_stats.csv"))
@@ -36,13 +36,13 @@ for name, k in (("K1", "fwd"), ("K2", "grad")):
     fk, wk = vals[(k, "FETCH_SIZE")], vals[(k, "WRITE_SIZE")]
     out["phnn_cartpole:euler:B65536:H50:stash"][name] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
                                                          "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
-out["note"] = ("separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --steps 3 (f16x2 kernels, stash = a2, q1, dH); "
+out["note"] = ("separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of bench.py --steps 3 (f16x2 kernels, stash = a2, q1, dH, R_net outputs); "
                "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halves wide streaming reads)")
 json.dump(out, open(os.path.join(dst, "traffic_measured.json"), "w"), indent=1)
 for tag in ("wgrad", "rk4"):  # per-kernel stats of the training pass (f4) and of config 5 on the RK4 stash
     m = glob.glob(os.path.join(src, f"trace_{tag}/**/*kernel_stats.csv"), recursive=True)
     if m:
-        shutil.copy(m[0], os.path.join(dst, f"{prefix}_{tag}_kernel_stats.csv"))
+        shutil.copy(max(m, key=os.path.getmtime), os.path.join(dst, f"{prefix}_{tag}_kernel_stats.csv"))
         shutil.copy(os.path.join(src, f"{tag}_probe.txt"), os.path.join(dst, f"{prefix}_{tag}_probe.txt"))
 for a, b in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"), ("other_configs.jsonl", "_other_configs.jsonl")):
     shutil.copy(os.path.join(src, a), os.path.join(dst, prefix + b))
