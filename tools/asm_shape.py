@@ -10,11 +10,11 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 asm = "/tmp/phnn_shape.s"
 key = sys.argv[1]
-adjoint = "grad" in key or "vjp" in key  # the adjoint kernels live in phnn_grad.hip, built with the max-ILP scheduler
+adjoint = "grad" in key or "vjp" in key  # the adjoint kernels live in phnn_grad.hip
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",  # as the Makefile
                 "--cuda-device-only", "-S", "-o", asm,
-                os.path.join(root, "phnn_mpc_amd/csrc", "phnn_grad.hip" if adjoint else "phnn_mpc.hip")]
-               + (["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"] if adjoint else []),
+                os.path.join(root, "phnn_mpc_amd/csrc", "phnn_grad.hip" if adjoint else "phnn_mpc.hip")],
                check=True, stderr=subprocess.DEVNULL)
 s = open(asm).read()
 key = sys.argv[1]
