@@ -228,6 +228,40 @@ def test_rollout_wgrad_vs_oracle_ragged(torch, name):
     assert torch.allclose(g_t + g_d, g1, rtol=0, atol=2e-5 * float(g1.abs().max()))
 
 
+def test_training_pass_full_size_tapes_vs_recompute(torch):
+    """The training pass at the bench's shape (B = 65536, H = 50, 3.3 M evaluation points): on K1's tapes (what
+    _RolloutFn does) and with the recomputing adjoint -- same parameter gradient to rounding, each bitwise repeatable,
+    and equal to the float64 oracle on a slice (the gradient of a slice's own loss)."""
+    from phnn_mpc_amd.engine import RolloutEngine
+    w = ol.load_weights("phnn_cartpole")
+    eng = RolloutEngine(w)
+    rng = np.random.default_rng(99)
+    B, H, dt = 65536, 50, 0.02
+    x0 = torch.tensor((rng.uniform(-1, 1, size=(B, 4)) * [1.0, 0.3, 0.5, 0.5]).astype(np.float32), device="cuda")
+    U = torch.tensor(rng.uniform(-5, 5, size=(B, H, 1)).astype(np.float32), device="cuda")
+    tb = torch.tensor(rng.normal(size=(B, H + 1, 4)).astype(np.float32), device="cuda") / B
+    res = {}
+    for tapes in (True, False):
+        runs = []
+        for _ in range(2):
+            traj = eng.rollout_trajectory(x0, U, "euler", dt, tapes=tapes)
+            g, gu, gx = eng.rollout_wgrad(x0, U, traj, "euler", dt, traj_bar=tb, tape_token=eng.tape_token if tapes else None)
+            runs.append((g.clone(), gu.clone()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+        res[tapes] = runs[0]
+    gmax = float(res[False][0].abs().max())
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5 * gmax
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6 * float(res[False][1].abs().max())
+    # a slice against the oracle: gradient of the slice's own loss (cotangents of the other rollouts do not enter it)
+    lo, n = 4321, 48
+    sl = slice(lo, lo + n)
+    traj = eng.rollout_trajectory(x0[sl], U[sl], "euler", dt, tapes=True)
+    g_s, _, _ = eng.rollout_wgrad(x0[sl], U[sl], traj, "euler", dt, traj_bar=tb[sl], tape_token=eng.tape_token)
+    ref = ol.OracleModel(w, "f64").rollout_wgrad(npy(x0[sl]).astype(np.float32), npy(U[sl]).astype(np.float32), "euler", dt,
+                                                  npy(tb[sl]).astype(np.float32), None)
+    check_named({k: npy(v) for k, v in eng.named_grads(g_s).items()}, oracle_named(w, ref["grad_theta"]), "full-size slice")
+
+
 def test_wgrad_other_matmul_modes_and_unsupported(torch, wg):
     """All-f32 products give the same gradients within tolerance; ODEFunc has no weight-gradient kernels and says so."""
     from phnn_mpc_amd.engine import PhnnError, RolloutEngine
