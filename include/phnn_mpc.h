@@ -225,6 +225,15 @@ size_t phnn_wgrad_workspace_bytes(const phnn_handle* h, int64_t B, int32_t H, in
 #define PHNN_WGRAD_TAPES 2      /* the workspace holds the tapes phnn_rollout_trajectory_ws wrote for the SAME
                                    (x0, u, B, H, integrator, dt) and weights; anything else gives wrong gradients */
 
+/* Layout of the records phnn_rollout_wgrad / phnn_model_wgrad leave at the start of the workspace: record r (one per
+ * 16-point tile and evaluation: tile-major, then step, then RK4 stage) starts at float r * record_floats; its
+ * per-point block starts small_offset floats in and holds small_stride floats for each of the tile's 16 points.  For
+ * CANONICAL handles with a MassMatrixNetwork (mass_type != PHNN_MASS_CARTPOLE) floats 20..23 of a point's block are the
+ * cotangent of the 2 x 2 matrix M(q) (row-major) of that evaluation and floats 24, 25 its q: the gradient of the mass
+ * network's parameters -- which the kernels leave at zero in grad_theta -- is one autograd pass of the caller's
+ * MassMatrixNetwork over those points (phnn_mpc_amd/models.py does exactly that); points beyond B carry zeros. */
+int phnn_wgrad_record_info(const phnn_handle* h, int32_t* record_floats, int32_t* small_offset, int32_t* small_stride);
+
 /* Reverse pass of the training rollout.  traj_dev: the states phnn_rollout_trajectory wrote; traj_bar_dev (B,H+1,n) and
  * dx_bar_dev (B,H,n): cotangents of the loss on X_pred and dX_pred (either may be NULL = 0).
  * -> grad_theta_dev (phnn_weight_count floats; overwritten, or added to with PHNN_WGRAD_ACCUMULATE), grad_u_dev (B,H,m)

@@ -28,7 +28,7 @@ LIB_PATH = os.environ.get("PHNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libph
 EXPORTED = [
     "phnn_create", "phnn_create_ex", "phnn_update_weights", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
     "phnn_model_vjp", "phnn_rollout_fwd", "phnn_workspace_bytes", "phnn_rollout_grad", "phnn_rollout_vjp",
-    "phnn_rollout_trajectory", "phnn_rollout_trajectory_ws", "phnn_wgrad_workspace_bytes", "phnn_rollout_wgrad", "phnn_model_wgrad",
+    "phnn_rollout_trajectory", "phnn_rollout_trajectory_ws", "phnn_wgrad_workspace_bytes", "phnn_wgrad_record_info", "phnn_rollout_wgrad", "phnn_model_wgrad",
     "phnn_adam_step", "phnn_plant_step", "phnn_shift_controls", "phnn_kernel_info", "phnn_variant_name",
     "phnn_version",
 ]
@@ -171,6 +171,8 @@ def load_library():
     lib.phnn_rollout_trajectory.restype = C.c_int
     lib.phnn_rollout_trajectory_ws.argtypes = [vp, f32p, f32p, i64, i32, i32, C.c_float, f32p, f32p, vp, vp]
     lib.phnn_rollout_trajectory_ws.restype = C.c_int
+    lib.phnn_wgrad_record_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.phnn_wgrad_record_info.restype = C.c_int
     lib.phnn_wgrad_workspace_bytes.argtypes = [vp, i64, i32, i32]
     lib.phnn_wgrad_workspace_bytes.restype = C.c_size_t
     lib.phnn_rollout_wgrad.argtypes = [vp, f32p, f32p, i64, i32, i32, C.c_float, f32p, f32p, f32p, vp, f32p, i32, f32p,

@@ -1345,7 +1345,10 @@ struct CanonModel {
                       const float* stash = nullptr, float* rec = nullptr, float Hbar = 0.f) {
     keep_lds_reads_local();
     if constexpr (MT != MASS_CARTPOLE) {
-      static_assert(!WG, "weight-gradient records: cart-pole mass matrix only");
+      // WG (MassMatrixNetwork): the record carries what H_net and R_diag_raw need, as below, plus -- per evaluation and
+      // rollout -- q and the cotangent Mb of the 2 x 2 matrix M(q) (small vectors 5, 6).  The mass network's own
+      // parameter gradient is then ONE autograd pass of the caller's MassMatrixNetwork module over those points
+      // (phnn_mpc_amd/models.py: mass_param_grads): it is a 2 -> 64 -> 64 -> 3 net outside the hot loop.
       float m[3], w[3];
       MTape mt;
       mass_eval(L, ln, y, m, w, mt);
@@ -1368,11 +1371,28 @@ struct CanonModel {
       const float dpb0 = lam[2] * w[0] + lam[3] * w[1], dpb1 = lam[2] * w[1] + lam[3] * w[2];    // W lam_v
       f32x4 v = {-dpb0, -dpb1, -Rd2 * dpb0, -Rd3 * dpb1};
       ubar = Base_Gt(L, dpb0, dpb1);
-      f32x4 zb = hnet_hvp<HID, MM>(L + oH, ln, tp, v);
+      if (WG) {
+        if (!ST) {
+          store_rec<T>(rec, ln, tp.a2);
+          store_rec<T>(rec + Rec::VEC, ln, tp.q1);
+        }
+        if (ln.q == 0) {
+          f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
+          sm[0] = z;
+          sm[1] = v;
+          sm[2] = lam;
+          sm[3] = dH;
+          sm[4] = f32x4{0.f, 0.f, -dpb0 * dH[2], -dpb1 * dH[3]};  // R_diag_raw rows 2, 3 (as the cart-pole branch)
+          sm[8] = u;
+          sm[9] = f32x4{Hbar, 0.f, 0.f, 0.f};
+        }
+      }
+      f32x4 zb = hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
+      if (WG) zb = zb + Hbar * dH;
       zb[2] += pb0;
       zb[3] += pb1;
       ybar = f32x4{zb[0], zb[1], zb[2] * m[0] + zb[3] * m[1], zb[2] * m[1] + zb[3] * m[2]};
-      if (MT >= MASS_DIAGONAL) {  // M(q) carries gradient: p = M qdot and the two uses of M^-1 (d W = -W dM W)
+      if (MT >= MASS_DIAGONAL || WG) {  // M(q) carries gradient: p = M qdot and the two uses of M^-1 (d W = -W dM W)
         const float W4[4] = {w[0], w[1], w[1], w[2]};
         const float Wb[4] = {lam[0] * z[2] + lam[2] * dp0, lam[0] * z[3] + lam[2] * dp1,
                              lam[1] * z[2] + lam[3] * dp0, lam[1] * z[3] + lam[3] * dp1};
@@ -1385,9 +1405,16 @@ struct CanonModel {
         Mb[1] = zb[2] * y[3] - Um[1];
         Mb[2] = zb[3] * y[2] - Um[2];
         Mb[3] = zb[3] * y[3] - Um[3];
-        f32x4 qb = mnet_bwd(L + oMn, ln, mt, mass_outputs_bar<MT>(mt.o, Mb));
-        ybar[0] += qb[0];
-        ybar[1] += qb[1];
+        if (WG && ln.q == 0) {
+          f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
+          sm[5] = f32x4{Mb[0], Mb[1], Mb[2], Mb[3]};
+          sm[6] = f32x4{y[0], y[1], 0.f, 0.f};
+        }
+        if (MT >= MASS_DIAGONAL) {
+          f32x4 qb = mnet_bwd(L + oMn, ln, mt, mass_outputs_bar<MT>(mt.o, Mb));
+          ybar[0] += qb[0];
+          ybar[1] += qb[1];
+        }
       }
       return;
     }
@@ -2530,6 +2557,17 @@ template <int HID, int MM, int MI>
 struct BlobOf<CanonModel<HID, MM, MI, MASS_CARTPOLE>> {
   static constexpr int oRd = 0;  // R_diag_raw (4) | G (4 MI) | log_a, b, log_c | H_net
   static constexpr BlobH<4, HID> H{4 + 4 * MI + 3};
+  static constexpr int SIZE = H.oW1 + H.size;
+};
+
+// MassMatrixNetwork variants: the mass block (L_tril, or the 64-wide padded M_net.mlp) sits where log_a, b, log_c do;
+// the kernels leave it untouched (its gradient comes from the module's own autograd pass over the recorded points)
+template <int HID, int MM, int MI, int MT>
+struct BlobOf<CanonModel<HID, MM, MI, MT>> {
+  static constexpr int oRd = 0;
+  static constexpr int MLP_OUT = MT == MASS_DIAGONAL ? 2 : 3;
+  static constexpr int MASS = MT == MASS_CONSTANT ? 4 : (64 * 2 + 64) + (64 * 64 + 64) + (MLP_OUT * 64 + MLP_OUT);
+  static constexpr BlobH<4, HID> H{4 + 4 * MI + MASS};
   static constexpr int SIZE = H.oW1 + H.size;
 };
 

@@ -573,8 +573,10 @@ std::vector<int> unpad_map(const phnn_desc* d, const phnn_desc* pd) {
   } else if (d->kind == PHNN_MODEL_CANONICAL) {
     const int W = pd->h_net.hidden[0];
     for (int k = 0; k < n; ++k) map[o + k] = (int)(p + k);  // R_diag_raw
-    o += (size_t)n + (size_t)n * m + 3;                     // G: buffer; log_a, b, log_c: constants to autograd
-    p += (size_t)n + (size_t)n * m + 3;
+    // G: buffer; the mass block (log_a, b, log_c: constants to autograd; MassMatrixNetwork: gradient formed outside the
+    // kernels, phnn_wgrad_record_info) carries no kernel gradient: -1
+    o += (size_t)n + (size_t)n * m + mass_block_count(d);
+    p += (size_t)n + (size_t)n * m + mass_block_count(pd);
     map_mlp(map, o, p, d->h_net, n, 1, W);
   }
   return map;
@@ -820,7 +822,7 @@ int check_cost(phnn_handle* h, const phnn_cost* c) {
 
 extern "C" {
 
-int phnn_version(void) { return 210; }
+int phnn_version(void) { return 220; }
 
 const char* phnn_variant_name(const phnn_handle* h) { return h ? h->ks.name : ""; }
 
@@ -1124,6 +1126,14 @@ static int wgrad_reduce(phnn_handle* h, void* workspace_dev, long long n_rec, fl
   if (e != hipSuccess) return hip_fail(h, e, "wgrad reduce launch");
   e = phnn_wgrad_finish(slab, rows, h->wg.blob_floats, h->d_unpad, h->n_params, grad_theta_dev, accumulate, st);
   if (e != hipSuccess) return hip_fail(h, e, "wgrad finish launch");
+  return PHNN_OK;
+}
+
+int phnn_wgrad_record_info(const phnn_handle* h, int32_t* record_floats, int32_t* small_offset, int32_t* small_stride) {
+  if (!h || !h->has_wgrad) return PHNN_ERR_UNSUPPORTED;
+  if (record_floats) *record_floats = h->wg.rec_floats;
+  if (small_offset) *small_offset = h->wg.rec_floats - kTileB * kRecSmall;
+  if (small_stride) *small_stride = kRecSmall;
   return PHNN_OK;
 }
 

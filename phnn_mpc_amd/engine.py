@@ -306,6 +306,19 @@ class RolloutEngine:
         _check(self.lib, self.h, rc)
         return grad_theta, xb, ub
 
+    def mass_cotangents(self, B, H=0, integrator="euler"):
+        """(q (P,2), Mbar (P,2,2)) of the evaluation points of the LAST rollout_wgrad(B, H, integrator) / model_wgrad(B
+        points, H = 0) call, read from the records in the weight-gradient workspace -- canonical models with a
+        MassMatrixNetwork: the cotangent of M(q) at every evaluation (phnn_wgrad_record_info).  P = 16 * records: points
+        beyond the batch carry zero cotangents."""
+        rf, so, ss = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(self.lib, self.h, self.lib.phnn_wgrad_record_info(self.h, C.byref(rf), C.byref(so), C.byref(ss)))
+        tiles = (int(B) + 15) // 16
+        n_rec = tiles if H <= 0 else tiles * int(H) * (4 if self._integ(integrator) == 1 else 1)
+        rec = self._wg_ws.view(torch.float32)[: n_rec * rf.value].view(n_rec, rf.value)
+        sm = rec[:, so.value:].reshape(n_rec * 16, ss.value)
+        return sm[:, 24:26], sm[:, 20:24].reshape(-1, 2, 2)
+
     def named_grads(self, grad_theta):
         """{state_dict key: tensor view of the parameter's shape} of a gradient blob."""
         return weights.unpack_grad_blob(None, grad_theta, layout=self.layout)

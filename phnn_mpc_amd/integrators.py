@@ -77,7 +77,8 @@ class _RolloutFn(torch.autograd.Function):
         if want_params or (db is not None and eng.has_wgrad):
             gth, gu, gx = eng.rollout_wgrad(y0d, ud, traj, ctx.integ, ctx.dt, traj_bar=tb, dx_bar=db,
                                             tape_token=ctx.tape_token)
-            pg = split_param_grads(eng, gth, ctx.keys, ctx.devs[2]) if want_params else (None,) * nk
+            pg = (split_param_grads(eng, gth, ctx.keys, ctx.devs[2], ctx.model, (y0d.shape[0], ud.shape[1], ctx.integ))
+                  if want_params else (None,) * nk)
             return (gx.to(ctx.devs[0]), gu.to(ctx.devs[1]), None, None, None, None) + pg
         if db is not None and bool((db != 0).any()):
             raise NotImplementedError("a loss on the per-step derivatives needs the weight-gradient kernels (pHNN / canonical)")

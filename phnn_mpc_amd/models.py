@@ -67,10 +67,28 @@ def grad_params(owner):
     return keys, [named[k] for k in keys]
 
 
-def split_param_grads(engine, grad_theta, keys, device):
-    """gradient blob -> tuple of per-parameter gradients in the order of `keys` (on `device`)."""
-    named = engine.named_grads(grad_theta)
+def split_param_grads(engine, grad_theta, keys, device, owner=None, points=None):
+    """gradient blob -> tuple of per-parameter gradients in the order of `keys` (on `device`).  owner + points
+    (B, H, integrator of the wgrad call just made): a canonical model with a MassMatrixNetwork gets the mass network's
+    parameter gradients from one autograd pass of that module over the recorded evaluation points (the kernels leave
+    them at zero and record q and the cotangent of M(q) instead; include/phnn_mpc.h: phnn_wgrad_record_info)."""
+    named = dict(engine.named_grads(grad_theta))
+    mass = getattr(owner, "M_net", None) if owner is not None else None
+    if (isinstance(mass, MassMatrixNetwork) and points is not None and hasattr(engine, "mass_cotangents")
+            and any(k.startswith("M_net.") for k in keys)):
+        q, Mb = engine.mass_cotangents(*points)
+        for k, g in mass_param_grads(mass, q, Mb).items():
+            named["M_net." + k] = g
     return tuple(named[k].to(device) for k in keys)
+
+
+def mass_param_grads(mass, q, Mbar):
+    """d sum_p <Mbar_p, M(q_p)> / d theta_M for a MassMatrixNetwork: {parameter name: gradient} on q's device (float32)."""
+    params = {k: p.detach().to(q.device, torch.float32).requires_grad_(True) for k, p in mass.named_parameters()}
+    with torch.enable_grad():
+        M = torch.func.functional_call(mass, params, (q.detach(),))
+        grads = torch.autograd.grad(M, list(params.values()), grad_outputs=Mbar.detach(), allow_unused=True)
+    return {k: (torch.zeros_like(p) if g is None else g) for (k, p), g in zip(params.items(), grads)}
 
 
 _warned_no_wgrad = set()
@@ -109,7 +127,8 @@ class _ModelFn(torch.autograd.Function):
         want_params = bool(ctx.keys) and any(ctx.needs_input_grad[4:])
         if want_params or (gH is not None and eng.has_wgrad):
             gth, xb, ub = eng.model_wgrad(xd, ud, gdx, None if gH is None else gH.to(eng.device, torch.float32))
-            pg = split_param_grads(eng, gth, ctx.keys, ctx.pdev) if want_params else (None,) * len(ctx.keys)
+            pg = (split_param_grads(eng, gth, ctx.keys, ctx.pdev, ctx.owner, (xd.shape[0], 0, "euler")) if want_params
+                  else (None,) * len(ctx.keys))
             return (xb.to(ctx.dev), ub.to(ctx.dev), None, None) + pg
         xb, ub = eng.vjp(xd, ud, gdx)
         return (xb.to(ctx.dev), ub.to(ctx.dev), None, None) + (None,) * len(ctx.keys)

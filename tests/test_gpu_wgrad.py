@@ -367,7 +367,7 @@ def test_mass_matrix_network_vs_reference(torch, name):
     g, ws = ol.load_named_golden("golden_mass.npz")
     w = ws[name]
     eng = RolloutEngine(w)
-    assert f"mass={name}" in eng.variant and not eng.has_wgrad
+    assert f"mass={name}" in eng.variant and eng.has_wgrad
     dx, H = eng.forward(g[f"{name}/x"], g[f"{name}/u"])
     assert np.abs(npy(dx) - g[f"{name}/fwd_dx"]).max() <= 2e-5 * np.abs(g[f"{name}/fwd_dx"]).max()
     assert np.abs(npy(H) - g[f"{name}/fwd_H"]).max() <= 2e-5 * max(1.0, np.abs(g[f"{name}/fwd_H"]).max())
@@ -400,3 +400,34 @@ def test_mass_matrix_network_vs_reference(torch, name):
     assert np.abs(npy(dy) - g[f"{name}/fwd_dx"]).max() <= 2e-5 * np.abs(g[f"{name}/fwd_dx"]).max()
     Mq = m.M_net(y[:, :2])
     assert Mq.shape == (64, 2, 2) and torch.allclose(torch.bmm(Mq, m.M_net.inverse(y[:, :2])), torch.eye(2).expand(64, 2, 2), atol=1e-5)
+    # parameter gradients (row f4 for these models): H_net and R_diag_raw from the kernels, the mass network's own
+    # parameters from one autograd pass of the module over the points the kernels record (q, cotangent of M(q)) --
+    # against the reference's gradients of sum lam . f + Hbar H (golden pt_g.*)
+    yg, ug = y.clone().requires_grad_(True), u.clone().requires_grad_(True)
+    dy, Hm, _ = m(yg, ug)
+    loss = (dy * torch.tensor(g[f"{name}/lam"])).sum() + (Hm * torch.tensor(g[f"{name}/Hbar"])).sum()
+    loss.backward()
+    ref = {k[len(name) + 6:]: g[k] for k in g if k.startswith(f"{name}/pt_g.")}
+    assert any(k.startswith("M_net.") for k in ref)
+    worst = check_named(_named_param_grads(m), ref, (name, "point wgrad"))
+    # rollouts (Euler and RK4, cotangents on X and dX) against the float64 oracle, every parameter incl. M_net's
+    from phnn_mpc_amd.integrators import rollout_trajectory_differentiable
+    m64 = ol.OracleModel(w, "f64")
+    rng = np.random.default_rng(3)
+    Br, Hr = 21, 12  # does not fill its two 16-point tiles
+    x0r = (rng.uniform(-1, 1, size=(Br, 4)) * [1.0, 0.3, 0.5, 0.5]).astype(np.float32)
+    Ur = rng.uniform(-3, 3, size=(Br, Hr, 1)).astype(np.float32)
+    tb = rng.normal(size=(Br, Hr + 1, 4)).astype(np.float32)
+    db = rng.normal(size=(Br, Hr, 4)).astype(np.float32)
+    for integ in ("euler", "rk4"):
+        for p_ in m.parameters():
+            p_.grad = None
+        X, dX = rollout_trajectory_differentiable(m, torch.tensor(x0r), torch.tensor(Ur), 0.02, integ, return_derivatives=True)
+        ((X * torch.tensor(tb)).sum() + (dX * torch.tensor(db)).sum()).backward()
+        oref = m64.rollout_wgrad(x0r, Ur, integ, 0.02, tb, db)
+        ours = _named_param_grads(m)
+        oref_named = {k: v for k, v in oracle_named(w, oref["grad_theta"]).items() if k in ours}  # parameters, not buffers (G, J)
+        assert any(k.startswith("M_net.") for k in oref_named)
+        w2 = check_named(ours, oref_named, (name, integ, "rollout wgrad"))
+        worst = max(worst, w2)
+    print(f"mass={name}: parameter gradients (incl. the mass network) worst tensor error {worst:.2e} of max|grad|")
