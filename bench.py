@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks ITSELF: the parent
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process before anything touches
+the GPU (it never imports torch), relays the child's output and exits with its return code.  A WORLD_SIZE that
+disagrees with --gpus is an error, so a scaling run can never silently report one GPU.
+
 A "step" is one pass of the hot path over one batch resident in HBM: K1 (fused forward march: clamp, pHNN
 dynamics, Euler step, stage cost over the whole horizon) then K2 (adjoint march -> d cost / d u), and, for
 N > 1, the one exchange the path has: an RCCL all-gather of the per-rollout costs.  Each rank works on its
@@ -68,6 +73,10 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch rollouts per GPU (default); strong: --global-batch rollouts split over the GPUs")
     ap.add_argument("--global-batch", type=int, default=65536, help="total rollouts with --scaling strong")
+    ap.add_argument("--rehearsal-engine", default=None, metavar="MODULE:FACTORY",
+                    help="REHEARSAL ONLY (tests/test_bench_spawn.py): run the multi-rank flow on CPU tensors with the engine "
+                         "FACTORY(weights) of MODULE (a stand-in that serves the engine protocol) and the gloo backend; the "
+                         "line is marked rehearsal and carries no roofline -- it is not a measurement")
     ap.add_argument("--config", default=None, choices=["headline", "config4"],
                     help="named workloads: headline = H=50, 65536 rollouts per GPU; config4 = BASELINE config 4, "
                          "2^20 rollouts over 8 GPUs = 131072 per GPU")
@@ -84,28 +93,73 @@ def synthetic_inputs(n, B, H, rank, u_amp):
     return x0, U
 
 
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start the N ranks as a CHILD torch.distributed.run and exit with its code.
+
+    Runs before torch is imported, so the parent never initialises the GPU (replacing or forking a process that has
+    is not allowed on the GPU boxes).  The child's stdout is relayed line by line: rank 0's JSON line is the last
+    line that parses as JSON; it is re-printed last so that a consumer reading the final line finds it."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(len(os.sched_getaffinity(0)) // args.gpus, 1)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line_json = None
+    for line in proc.stdout:
+        try:
+            if isinstance(json.loads(line), dict):
+                line_json = line
+                continue
+        except ValueError:
+            pass
+        sys.stdout.write(line)
+    rc = proc.wait()
+    if line_json is not None:
+        sys.stdout.write(line_json)
+    sys.stdout.flush()
+    if rc == 0 and line_json is None:
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # a launcher started another number of ranks than the line would claim: refuse
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it with "
+                 f"--nproc-per-node {args.gpus} (or plain `python bench.py --gpus {args.gpus}`, which launches the ranks itself)")
+    import torch
+    import torch.distributed as dist
+
+    rehearsal = args.rehearsal_engine is not None
     # PHNN_BENCH_BACKEND=gloo lets the N>1 flow be rehearsed with several ranks on ONE GPU (RCCL refuses two ranks
     # on a device); the driver's runs use the default, nccl (= RCCL) with one GPU per rank.
-    backend = os.environ.get("PHNN_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    backend = "gloo" if rehearsal else os.environ.get("PHNN_BENCH_BACKEND", "nccl")
+    dev_index = 0 if rehearsal else local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(dev_index)
+        if not rehearsal:
+            torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev = torch.device("cuda", dev_index)
+    dev = torch.device("cpu") if rehearsal else torch.device("cuda", dev_index)
+    collective = {"nccl": "RCCL all-gather of costs", "gloo": "gloo all-gather of costs through host copies (rehearsal backend)"
+                  }.get(backend, f"{backend} all-gather of costs")
 
     from phnn_mpc_amd import _capi
     from phnn_mpc_amd.distributed import shard_bounds
@@ -114,7 +168,12 @@ def main():
     gold = os.path.join(ROOT, "tests", "golden")
     with np.load(os.path.join(gold, f"weights_{args.model}.npz")) as z:
         w = {k: z[k] for k in z.files}
-    eng = RolloutEngine(w, dev, matmul=args.matmul)
+    if rehearsal:  # a CPU stand-in behind the engine protocol: exercises the launch / shard / gather flow only
+        import importlib
+        mod, fac = args.rehearsal_engine.split(":")
+        eng = getattr(importlib.import_module(mod), fac)(w)
+    else:
+        eng = RolloutEngine(w, dev, matmul=args.matmul)
     if args.config == "config4":
         args.batch = 131072
     if args.scaling == "strong":  # fixed total work: the global batch is split contiguously over the ranks
@@ -196,7 +255,52 @@ def main():
             assert torch.isfinite(c_last).all(), "non-finite cost in the bench workload"
             return el, k1, k2
 
-    main_wl = Workload(eng, B, B_pad, stash=not args.no_stash)
+    class RehearsalWorkload(Workload):
+        """The same flow -- K1, all-gather of the costs, K2, barriers, max over ranks -- on a CPU stand-in engine
+        (engine protocol: rollout_cost_grad(..., after_forward=)).  Host clocks; not a measurement."""
+
+        def __init__(self, engine, Bk, Bk_pad, stash=True):
+            self.eng, self.B, self.stash = engine, Bk, None
+            self.c_pad = torch.zeros(Bk_pad, dtype=torch.float32)
+            self.gathered = torch.empty(world * Bk_pad, dtype=torch.float32) if world > 1 else None
+            self.mark = [0.0, 0.0, 0.0]
+
+        def step(self, ev=None):
+            self.mark[0] = time.perf_counter()
+
+            def gather(c):
+                self.mark[1] = time.perf_counter()
+                self.c_pad[: self.B] = c
+                if world > 1:
+                    dist.all_gather_into_tensor(self.gathered, self.c_pad)
+
+            c, _ = self.eng.rollout_cost_grad(x0[: self.B], U[: self.B], cost, args.integrator, dt, after_forward=gather)
+            self.mark[2] = time.perf_counter()
+            if ev is not None:
+                ev.extend(self.mark)
+            return c
+
+        def timed(self, steps, warmup):
+            for _ in range(warmup):
+                self.step()
+            if world > 1:
+                dist.barrier()
+            marks = [[] for _ in range(steps)]
+            t0 = time.perf_counter()
+            for k in range(steps):
+                c_last = self.step(marks[k])
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            assert torch.isfinite(c_last).all()
+            return el, 1e3 * float(np.mean([m[1] - m[0] for m in marks])), 1e3 * float(np.mean([m[2] - m[1] for m in marks]))
+
+    WL = RehearsalWorkload if rehearsal else Workload
+    main_wl = WL(eng, B, B_pad, stash=not args.no_stash)
     ws_stash = main_wl.stash
     elapsed, k1_ms, k2_ms = main_wl.timed(args.steps, args.preheat + args.warmup)
 
@@ -209,22 +313,26 @@ def main():
             del main_wl
             torch.cuda.empty_cache()
             ks = max(min(args.steps, 50), 1)
-            el_s, k1s, k2s = Workload(eng, Bs, Bs_pad, stash=not args.no_stash).timed(ks, 3)
+            el_s, k1s, k2s = WL(eng, Bs, Bs_pad, stash=not args.no_stash).timed(ks, 3)
             strong = {"global_batch": args.global_batch, "batch_per_gpu": Bs_pad, "steps": ks,
                       "value": round(args.global_batch * ks / el_s, 1), "ms_per_step": round(1e3 * el_s / ks, 4),
                       "k1_launch_ms": round(k1s, 4), "k2_launch_ms": round(k2s, 4)}
     # the 24-bit-exact product modes, short timed loops in the same run (single GPU only)
     other_modes = None
-    if world == 1 and not args.no_other_modes and args.model in ("phnn_cartpole", "canonical_cartpole"):
+    if world == 1 and not rehearsal and not args.no_other_modes and args.model in ("phnn_cartpole", "canonical_cartpole"):
         other_modes = {}
         for mode in ("bf16x3", "f32"):
             if mode == eng.matmul_mode:
                 continue
             e2 = RolloutEngine(w, dev, matmul=mode)
-            ko = max(min(args.steps, 10), 1)
-            el_o, k1o, k2o = Workload(e2, B, B_pad, stash=not args.no_stash).timed(ko, 2)
-            other_modes[mode] = {"value": round(B * ko / el_o, 1), "steps": ko, "k1_launch_ms": round(k1o, 4),
-                                 "k2_launch_ms": round(k2o, 4), "kernel_variant": e2.variant}
+            ko = max(min(args.steps, 50), 1)  # same warm-up as the main loop (first launches load the code objects)
+            el_o, k1o, k2o = Workload(e2, B, B_pad, stash=not args.no_stash).timed(ko, args.preheat + args.warmup)
+            pk = PEAK_F32_MFMA if mode == "f32" else PEAK_16BIT_MFMA / SPLIT_PRODUCTS[mode]
+            fl = B * H * (4 if args.integrator == "rk4" else 1) * FLOP_VJP
+            other_modes[mode] = {"value": round(B * ko / el_o, 1), "steps": ko, "warmup": args.preheat + args.warmup,
+                                 "k1_launch_ms": round(k1o, 4), "k2_launch_ms": round(k2o, 4), "kernel_variant": e2.variant,
+                                 "roofline": {"kernel": "k_rollout_grad", "achieved": round(fl / (k2o * 1e-3) / 1e12, 3),
+                                              "peak": round(pk / 1e12, 1), "unit": "TFLOP/s", "frac": round(fl / (k2o * 1e-3) / pk, 4)}}
             e2.close()
 
     if rank == 0:
@@ -246,7 +354,7 @@ def main():
             traffic_k1 = entry.get("K1", {}).get("hbm_bytes_per_launch")
         except OSError:
             pass
-        mm = eng.matmul_mode
+        mm = getattr(eng, "matmul_mode", "f32")
         peak = PEAK_F32_MFMA if mm == "f32" else PEAK_16BIT_MFMA / SPLIT_PRODUCTS[mm]
         roof = {
             "bound": "mfma", "kernel": "k_rollout_grad", "achieved": round(ach / 1e12, 3), "peak": round(peak / 1e12, 1),
@@ -273,18 +381,28 @@ def main():
             cpu = cpu_baseline(w, cost, x0_h, U_h, args.integrator, dt, args.cpu_sample)
             if args.model == "phnn_cartpole" and args.integrator == "euler":
                 cpu_torch = cpu_baseline_torch(w, x0_h, U_h, dt, umax)
+        # the labels follow the workload actually run (the default run reproduces BASELINE.json's metric wording)
+        short = {"phnn_cartpole": "cartpole", "canonical_cartpole": "cartpole pHNN_canonical", "phnn_pendulum": "pendulum",
+                 "odefunc_pendulum": "pendulum ODEFunc"}[args.model]
+        batch_lbl = f"batch={B}" if args.scaling == "weak" else f"global batch={total} (strong scaling, {B_pad}/GPU)"
         out = {
-            "metric": "pHNN-MPC rollouts+grads/sec, cartpole H=50 batch=65536", "value": round(value, 1),
+            "metric": f"pHNN-MPC rollouts+grads/sec, {short}{'' if args.integrator == 'euler' else ' RK4'} H={H} {batch_lbl}",
+            "value": round(value, 1),
             "unit": "rollouts+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_steps": args.preheat,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} (seed-0 fixture weights) {args.integrator} H={H} "
                                    f"B={B}/GPU: rollout + stage cost (K1) + control gradient (K2)"
-                                   + (" + RCCL all-gather of costs" if world > 1 else ""),
-                       "k2_mode": "stash" if ws_stash is not None else "recompute", "matmul": eng.matmul_mode,
-                       "kernel_variant": eng.variant, "horizon": H, "batch_per_gpu": B_pad, "global_batch": total, "parallelism": f"shard{world}"},
+                                   + (f" + {collective}" if world > 1 else ""),
+                       "k2_mode": "stash" if ws_stash is not None else "recompute", "matmul": mm,
+                       "kernel_variant": getattr(eng, "variant", type(eng).__name__), "horizon": H, "batch_per_gpu": B_pad,
+                       "global_batch": total, "parallelism": f"shard{world}", "collective_backend": backend if world > 1 else None},
             "roofline": roof,
         }
+        if rehearsal:  # the flow ran on a CPU stand-in: the line proves the launch / shard / gather plumbing, nothing else
+            out["rehearsal"] = True
+            out["data"] = "synthetic (REHEARSAL: CPU stand-in engine, host clocks -- not a measurement)"
+            out["roofline"] = None
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if cpu_torch is not None:

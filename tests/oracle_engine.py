@@ -93,3 +93,8 @@ class OracleEngine:
             assert t.dtype == torch.float32 and t.is_contiguous()
         lib.oracle_adam_f32(C.c_void_p(u.data_ptr()), C.c_void_p(grad.data_ptr()), C.c_void_p(exp_avg.data_ptr()),
                             C.c_void_p(exp_avg_sq.data_ptr()), u.numel(), lr, beta1, beta2, eps, step)
+
+
+def bench_rehearsal_engine(state_dict):
+    """Factory for `bench.py --rehearsal-engine oracle_engine:bench_rehearsal_engine` (tests/test_bench_spawn.py)."""
+    return OracleEngine(state_dict)
