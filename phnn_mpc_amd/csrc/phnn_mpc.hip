@@ -729,6 +729,7 @@ struct phnn_handle {
   int n_params;      // floats of the original blob
   float* d_img;
   float* h_img;      // pinned staging copy of the image (phnn_update_weights uploads from it asynchronously)
+  hipEvent_t up_done;  // recorded behind the last asynchronous upload from h_img (null until the first one)
   size_t img_floats;
   int n_cu;
   int max_waves;
@@ -887,6 +888,7 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   h->max_waves = opt.max_waves > 0 ? opt.max_waves : kMaxWaves;
   h->d_img = nullptr;
   h->h_img = nullptr;
+  h->up_done = nullptr;
   h->d_unpad = nullptr;
   h->n_params = (int)n_floats;
   kernel_set(v, &h->ks);
@@ -971,12 +973,24 @@ int phnn_update_weights(phnn_handle* h, const float* weights_host, size_t n_floa
   if (v != h->variant || img.size() != h->img_floats) return fail(h, PHNN_ERR_INVALID_ARG, "weights select another kernel variant");
   PHNN_ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
-  // the pinned staging buffer may still feed the previous asynchronous upload: wait for this stream first
-  hipError_t e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return hip_fail(h, e, "hipStreamSynchronize");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(h, PHNN_ERR_INVALID_ARG, "phnn_update_weights packs on the host and cannot be captured into a graph");
+  // the pinned staging buffer may still feed the PREVIOUS asynchronous upload (on whatever stream that one used):
+  // wait for the event recorded behind it -- not for the caller's stream, which may be another one and busy
+  hipError_t e;
+  if (h->up_done) {
+    e = hipEventSynchronize(h->up_done);
+    if (e != hipSuccess) return hip_fail(h, e, "hipEventSynchronize(previous weight upload)");
+  } else {
+    e = hipEventCreateWithFlags(&h->up_done, hipEventDisableTiming);
+    if (e != hipSuccess) return hip_fail(h, e, "hipEventCreate");
+  }
   memcpy(h->h_img, img.data(), sizeof(float) * img.size());
   e = hipMemcpyAsync(h->d_img, h->h_img, sizeof(float) * img.size(), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return hip_fail(h, e, "hipMemcpyAsync(weights image)");
+  e = hipEventRecord(h->up_done, st);
+  if (e != hipSuccess) return hip_fail(h, e, "hipEventRecord");
   return PHNN_OK;
 }
 
@@ -984,6 +998,7 @@ int phnn_destroy(phnn_handle* h) {
   if (!h) return PHNN_OK;
   if (h->d_img) (void)hipFree(h->d_img);
   if (h->h_img) (void)hipHostFree(h->h_img);
+  if (h->up_done) (void)hipEventDestroy(h->up_done);
   if (h->d_unpad) (void)hipFree(h->d_unpad);
   delete h;
   return PHNN_OK;

@@ -280,6 +280,10 @@ class RolloutEngine:
         ws = self._wgrad_workspace(B, H, integ)
         use_tapes = (tape_token is not None and tape_token == self._tape_token
                      and tape_token[1:] == (B, H, integ, float(dt)))
+        if not use_tapes:
+            # records and slab of THIS shape start at offset 0 of the shared workspace and may reach into the tape region
+            # of whatever (smaller / other-shaped) rollout left its tapes there: those tapes are no longer trustworthy
+            self._tape_token = None
         flags = (_capi.WGRAD_ACCUMULATE if accumulate else 0) | (_capi.WGRAD_TAPES if use_tapes else 0)
         rc = self.lib.phnn_rollout_wgrad(self.h, self._p(x0), self._p(u), B, H, integ, float(dt), self._p(traj),
                                          self._p(tb), self._p(db), self._p(ws), self._p(grad_theta), flags,

@@ -100,7 +100,8 @@ def _no_wgrad_warning(owner):
         _warned_no_wgrad.add(name)
         import warnings
         warnings.warn(f"{name}: the engine has no weight-gradient kernels for this model family; backward() leaves "
-                      "its parameters without .grad (gradients w.r.t. inputs are exact)", RuntimeWarning, stacklevel=3)
+                      "its parameters without .grad.  Gradients w.r.t. x and u of the dx output are exact; a cotangent on "
+                      "the H output raises NotImplementedError (the plain VJP kernel has no H input)", RuntimeWarning, stacklevel=3)
 
 
 class _ModelFn(torch.autograd.Function):
@@ -130,6 +131,11 @@ class _ModelFn(torch.autograd.Function):
             pg = (split_param_grads(eng, gth, ctx.keys, ctx.pdev, ctx.owner, (xd.shape[0], 0, "euler")) if want_params
                   else (None,) * len(ctx.keys))
             return (xb.to(ctx.dev), ub.to(ctx.dev), None, None) + pg
+        if gH is not None and getattr(eng, "kind", None) != _capi.MODEL_ODEFUNC and bool((gH != 0).any()):
+            # only the record-emitting VJP (has_wgrad) takes a cotangent on H; dropping it would return wrong x / u
+            # gradients for a loss through H (e.g. an energy-anchor term) without any sign of it
+            raise NotImplementedError("backward through the H output needs the weight-gradient kernels, which this model "
+                                      "variant / matmul mode does not have (has_wgrad is False)")
         xb, ub = eng.vjp(xd, ud, gdx)
         return (xb.to(ctx.dev), ub.to(ctx.dev), None, None) + (None,) * len(ctx.keys)
 
@@ -155,7 +161,9 @@ class _EngineBacked(nn.Module):
 
     def _fingerprint(self):
         """Cheap identity of the current parameter values: (storage pointer, in-place version counter) of every
-        parameter and buffer.  An optimizer step, copy_(), an in-place edit or a re-assigned .data changes it."""
+        parameter and buffer.  An optimizer step, copy_(), an in-place edit of the parameter itself or a re-assigned
+        .data changes it.  NOT caught: in-place edits made THROUGH `p.data` (p.data.mul_(..), p.data -= ..) -- they bump
+        neither the pointer nor p._version; call refresh_engine() after such edits."""
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     @property

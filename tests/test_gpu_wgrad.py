@@ -222,6 +222,20 @@ def test_rollout_wgrad_vs_oracle_ragged(torch, name):
         assert torch.equal(g_stale, g1)
         eng.update_weights(w)
         assert eng.tape_token is None
+    # a no-tape wgrad call of a LARGER shape in the pre-grown workspace writes its records over a smaller rollout's
+    # tapes: the small rollout's old token must not be honoured any more (the engine drops it; recompute path, oracle-exact)
+    Bs, Hs = 20, 5
+    x0s, Us = x0[:Bs].copy(), U[:Bs, :Hs].copy()
+    tbs, dbs = tb[:Bs, : Hs + 1].copy(), db[:Bs, :Hs].copy()
+    refs = m64.rollout_wgrad(x0s, Us, "euler", dt, tbs, dbs)
+    traj_s = eng.rollout_trajectory(x0s, Us, "euler", dt, tapes=True)
+    tok_s = eng.tape_token
+    assert tok_s is not None
+    eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb, dx_bar=db)  # B = 300, H = 16, no token: records from offset 0
+    assert eng.tape_token is None
+    gs, gus, _ = eng.rollout_wgrad(x0s, Us, traj_s, "euler", dt, traj_bar=tbs, dx_bar=dbs, tape_token=tok_s)
+    check_named({k: npy(v) for k, v in eng.named_grads(gs).items()}, oracle_named(w, refs["grad_theta"]), (name, "stale small tapes"))
+    assert np.abs(npy(gus) - refs["grad_u"]).max() <= TOL * np.abs(refs["grad_u"]).max()
     # only one of the two cotangents
     g_t, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, traj_bar=tb)
     g_d, _, _ = eng.rollout_wgrad(x0, U, traj, integ, dt, dx_bar=db)

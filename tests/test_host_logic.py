@@ -168,6 +168,28 @@ def test_model_forward_through_engine_protocol():
     assert dx1.shape == (1, 4) and H1.shape == (1,)
 
 
+def test_backward_through_H_without_wgrad_kernels_raises():
+    """A variant without weight-gradient kernels (bf16x3, 64-wide f16x2) has only the plain VJP, which takes no cotangent
+    on H: a loss through H must raise instead of silently dropping that term."""
+    w = ol.load_weights("phnn_cartpole")
+    g = ol.load_golden("phnn_cartpole")
+    m = pHNN(CFG)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    eng = OracleEngine(w)
+    eng.has_wgrad = False
+    m.set_engine(eng)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = torch.tensor(g["fwd_x"][:4], requires_grad=True)
+    u = torch.tensor(g["fwd_u"][:4])
+    dx, H = m(x, u)
+    with pytest.raises(NotImplementedError):
+        (dx.sum() + H.sum()).backward()
+    dx, H = m(x, u)
+    dx.sum().backward()  # the dx output alone is fine
+    assert x.grad is not None
+
+
 def test_unsupported_model_options_raise():
     cfg = yaml.safe_load(open(CFG))
     cfg["model"]["H_mlp"]["activation"] = "nn.ReLU"
