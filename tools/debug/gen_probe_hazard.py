@@ -34,6 +34,22 @@ TESTS = {
     "raw_valu_to_srcB": (f"v_mov_b32 v46, 0\nv_mov_b32 v47, 0\ns_nop 7\nv_mov_b32 v46, v44\nv_mov_b32 v47, v44\n{{F}}{MF} v[56:59], v[40:43], v[44:47], v[48:51]\n", 56, 1),
     "raw_pk_to_srcB": (f"v_mov_b32 v46, 0\nv_mov_b32 v47, 0\ns_nop 7\nv_pk_mov_b32 v[46:47], v[44:45], v[44:45]\n{{F}}{MF} v[56:59], v[40:43], v[44:47], v[48:51]\n", 56, 1),
     "raw_pk_to_srcC": (f"v_pk_mul_f32 v[50:51], v[48:49], v[72:73]\n{{F}}{MF} v[56:59], v[40:43], v[44:47], v[48:51]\n", 56, 1),
+    # destination overlapping an input operand (the register allocator does this when the operand dies at the MFMA)
+    "dst_eq_srcB": (f"{{F}}{MF} v[44:47], v[40:43], v[44:47], v[48:51]\n", 44, 1),
+    "dst_eq_srcA": (f"{{F}}{MF} v[40:43], v[40:43], v[44:47], v[48:51]\n", 40, 1),
+    # ... followed by a dependent MFMA that takes the result as C and ALSO overwrites its own B (the packed build's pattern)
+    "dst_eq_srcB_chain": (f"v_mov_b32 v52, v44\nv_mov_b32 v53, v44\nv_mov_b32 v54, v44\nv_mov_b32 v55, v44\ns_nop 3\n"
+                          f"{MF} v[44:47], v[40:43], v[44:47], v[48:51]\n{{F}}{MF} v[52:55], v[40:43], v[52:55], v[44:47]\n", 52, 2),
+    # an LDS load overwriting an operand of the MFMA just issued (write-after-read by an asynchronous writer): the LDS word
+    # holds zeros; the load lands a while later -- the MFMA must have read its operand by then
+    "war_srcA_lds": (f"{MF} v[56:59], v[40:43], v[44:47], v[48:51]\n{{F}}ds_read_b128 v[40:43], v77\ns_waitcnt lgkmcnt(0)\n", 56, 1),
+    "war_srcC_lds": (f"{MF} v[56:59], v[40:43], v[44:47], v[48:51]\n{{F}}ds_read_b128 v[48:51], v77\ns_waitcnt lgkmcnt(0)\n", 56, 1),
+    # the ADDRESS register of an LDS read overwritten right behind it (three more reads queued ahead, as in the kernels'
+    # fragment loads): must return the 5.0 stored at the original address, not the 9.0 at address + 8192
+    "war_lds_addr_valu": (f"ds_read_b128 v[64:67], v77\nds_read_b128 v[68:71], v77 offset:16\nds_read_b128 v[52:55], v77 offset:32\n"
+                          f"ds_read_b128 v[56:59], v77\n{{F}}v_add_u32_e32 v77, 0x2000, v77\ns_waitcnt lgkmcnt(0)\n", 56, "5.0f"),
+    "war_lds_addr_valu_tr": (f"ds_read_b128 v[64:67], v77\nds_read_b128 v[68:71], v77 offset:16\nds_read_b64_tr_b16 v[52:53], v77 offset:32\n"
+                             f"ds_read_b64_tr_b16 v[56:57], v77\nds_read_b64_tr_b16 v[58:59], v77\n{{F}}v_add_u32_e32 v77, 0x2000, v77\ns_waitcnt lgkmcnt(0)\n", 56, "5.0f"),
     "raw_cvt_to_srcB": (f"v_mov_b32 v47, 0\ns_nop 7\nv_cvt_pk_f16_f32 v47, v76, v76\n{{F}}{MF} v[56:59], v[40:43], v[44:47], v[48:51]\n", 56, 1),
 }
 
@@ -49,6 +65,7 @@ names = []
 for tname, (seq, rreg, mult) in TESTS.items():
     for fname, fins in FILLS.items():
         for K in KS:
+            expr = mult if isinstance(mult, str) else f"cv + {mult}.0f * 32.0f * (float)(al * be)"
             kn = f"k_{tname}_{fname}_{K}"
             names.append((kn, tname, fname, K))
             body = seq.replace("{F}", (fins + "\n") * K)
@@ -59,7 +76,7 @@ for tname, (seq, rreg, mult) in TESTS.items():
                 "v_mov_b32 v52, %[s]\nv_mov_b32 v53, %[s]\nv_mov_b32 v54, %[s]\nv_mov_b32 v55, %[s]\n"
                 "v_mov_b32 v56, %[s]\nv_mov_b32 v57, %[s]\nv_mov_b32 v58, %[s]\nv_mov_b32 v59, %[s]\n"
                 "v_mov_b32 v60, 0\nv_mov_b32 v62, 1.0\nv_mov_b32 v63, 1.0\nv_mov_b32 v72, 1.0\nv_mov_b32 v73, 1.0\n"
-                "v_mov_b32 v74, 0\nv_mov_b32 v75, 0\nv_mov_b32 v76, %[bf]\n"
+                "v_mov_b32 v74, 0\nv_mov_b32 v75, 0\nv_mov_b32 v76, %[bf]\nv_mov_b32 v77, %[la]\n"
                 "s_nop 7\ns_nop 7\n"
                 # two independent MFMAs queued ahead of the test sequence: the producer meets a busy matrix pipe
                 f"{MF} v[64:67], v[40:43], v[44:47], 0\n{MF} v[68:71], v[40:43], v[44:47], 0\n"
@@ -71,6 +88,9 @@ for tname, (seq, rreg, mult) in TESTS.items():
             asm_c = "\n".join('      "' + l + '\\n"' for l in asm.strip().split("\n"))
             w(f"""__global__ __launch_bounds__(512) void {kn}(Res* res, int slot) {{
   const int wave = threadIdx.x >> 6;
+  __shared__ float zeros[2 * 512 * 4];  // first 8 KB: 5.0, second 8 KB: 9.0 (LDS address tests read the first half)
+  for (int j = threadIdx.x; j < 2 * 512 * 4; j += blockDim.x) zeros[j] = j < 512 * 4 ? 5.0f : 9.0f;
+  __syncthreads();
   unsigned bad = 0, fg = 0, fe = 0;
   for (int it = 0; it < ITER; ++it) {{
     const int al = 1 + (it + wave) % 3, be = 1 + (it * 7 + blockIdx.x) % 3;
@@ -81,10 +101,10 @@ for tname, (seq, rreg, mult) in TESTS.items():
     asm volatile(
 {asm_c}
       : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
-      : [a] "v"(f16pair(al)), [b] "v"(f16pair(be)), [c] "v"(cv), [s] "v"(-7777.0f), [bf] "v"((float)be)
+      : [a] "v"(f16pair(al)), [b] "v"(f16pair(be)), [c] "v"(cv), [s] "v"(-7777.0f), [bf] "v"((float)be), [la] "v"((unsigned)(threadIdx.x * 16) + (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)zeros)
       : "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59",
-        "v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76");
-    const float exp = cv + {mult}.0f * 32.0f * (float)(al * be);
+        "v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","memory");
+    const float exp = {expr};
     if (r0 != exp || r1 != exp || r2 != exp || r3 != exp) {{
       if (!bad) {{ fg = __builtin_bit_cast(unsigned, r0 != exp ? r0 : (r1 != exp ? r1 : (r2 != exp ? r2 : r3))); fe = __builtin_bit_cast(unsigned, exp); }}
       ++bad;

@@ -16,7 +16,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-enum { ROLE_NONE = 0, ROLE_M = 1, ROLE_P = 2, ROLE_V = 3, ROLE_X = 4, ROLE_SG = 5 };
+enum { ROLE_NONE = 0, ROLE_M = 1, ROLE_P = 2, ROLE_V = 3, ROLE_X = 4, ROLE_SG = 5, ROLE_MG = 6 };
 
 __device__ unsigned role_m(int n, int al, int be) {
   f16x8 a, b;
@@ -31,6 +31,29 @@ __device__ unsigned role_m(int n, int al, int be) {
   const float e = (float)n * 32.0f * (float)(al * be);
   unsigned bad = 0;
   for (int r = 0; r < 4; ++r) bad += (c0[r] != e) + (c1[r] != e) + (c2[r] != e) + (c3[r] != e);
+  return bad;
+}
+
+// MFMA chains with idle gaps of varying length between the instructions (the matrix pipe goes idle and is re-entered
+// while the partner wave's stream is in flight)
+__device__ unsigned role_mg(int n, int al, int be) {
+  f16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(float)al; b[j] = (_Float16)(float)be; }
+  f32x4 c0 = {0, 0, 0, 0}, c1 = c0;
+  for (int k = 0; k < n; ++k) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    asm volatile("s_nop 15");
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    if (k & 1) asm volatile("s_nop 9");
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    if (k & 2) asm volatile("s_nop 4");
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+  }
+  const float e = (float)n * 3.0f * 32.0f * (float)(al * be);
+  unsigned bad = 0;
+  for (int r = 0; r < 4; ++r) bad += (c0[r] != e) + (c1[r] != e);
   return bad;
 }
 
@@ -101,6 +124,7 @@ __device__ unsigned run_role(int role, int n, int al, int be) {
     case ROLE_V: return role_v(n);
     case ROLE_X: return role_x(n, al, be);
     case ROLE_SG: return role_sg(n);
+    case ROLE_MG: return role_mg(n, al, be);
     default: return 0;
   }
 }
@@ -116,10 +140,11 @@ __global__ __launch_bounds__(512) void k(int roleA, int roleB, int n, unsigned* 
 
 int main(int argc, char** argv) {
   const int rounds = argc > 1 ? atoi(argv[1]) : 20;
-  const char* names[] = {"none", "mfma16", "pk", "valu", "mfma16+pk same wave", "f32 mfma"};
+  const char* names[] = {"none", "mfma16", "pk", "valu", "mfma16+pk same wave", "f32 mfma", "mfma16 with gaps"};
   const int pairs[][2] = {{ROLE_M, ROLE_NONE}, {ROLE_M, ROLE_M}, {ROLE_M, ROLE_V}, {ROLE_M, ROLE_P}, {ROLE_P, ROLE_M},
                           {ROLE_X, ROLE_NONE}, {ROLE_X, ROLE_X}, {ROLE_X, ROLE_P}, {ROLE_M, ROLE_X}, {ROLE_SG, ROLE_P},
-                          {ROLE_SG, ROLE_V}, {ROLE_P, ROLE_P}, {ROLE_M, ROLE_SG}, {ROLE_X, ROLE_SG}};
+                          {ROLE_SG, ROLE_V}, {ROLE_P, ROLE_P}, {ROLE_M, ROLE_SG}, {ROLE_X, ROLE_SG},
+                          {ROLE_MG, ROLE_NONE}, {ROLE_MG, ROLE_P}, {ROLE_P, ROLE_MG}, {ROLE_MG, ROLE_X}, {ROLE_MG, ROLE_MG}, {ROLE_MG, ROLE_V}, {ROLE_MG, ROLE_M}};
   unsigned* d;
   if (hipMalloc(&d, 2 * sizeof(unsigned)) != hipSuccess) return 1;
   printf("%-24s %-24s %14s %14s   (mismatching values over %d launches of 1024 workgroups, n = 2000 rounds per wave)\n",
