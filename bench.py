@@ -399,6 +399,13 @@ def main():
                        "global_batch": total, "parallelism": f"shard{world}", "collective_backend": backend if world > 1 else None},
             "roofline": roof,
         }
+        try:  # which product mode the parity margin measured on TRAINED weights allows (tests/parity_margin_trained.py)
+            with open(os.path.join(ROOT, "profiles", "parity_margin_trained.json")) as f:
+                pm = json.load(f)
+            out["config"]["trained_weights_margin"] = {"mode": mm, "cost_grad": pm.get(mm), "unit": pm.get("unit"),
+                                                        "reading": pm.get("reading")}
+        except (OSError, ValueError):
+            pass
         if rehearsal:  # the flow ran on a CPU stand-in: the line proves the launch / shard / gather plumbing, nothing else
             out["rehearsal"] = True
             out["data"] = "synthetic (REHEARSAL: CPU stand-in engine, host clocks -- not a measurement)"

@@ -586,6 +586,41 @@ DEV void load_act(const float* src, Lane ln, Act<T>& a) {
   }
 }
 
+// 24-bit fixed-point tape for vectors that are tanh OUTPUTS (|a| <= 1): q = rint(a (2^23 - 1)), four values in three
+// dwords per lane, one coalesced 768 B store / load per tile.  Absolute error <= 6e-8 -- below the 2.5e-7 of the kernels'
+// own tanh -- for 25 % fewer tape bytes.  Used where BOTH march kernels are bound by the tape's HBM stream (the ODEFunc
+// model: K1 / K2 of BASELINE config 5 moved 54.5 GB each way at 3.6 TB/s with the matrix pipe mostly idle); the pHNN
+// adjoint is bound by vector-instruction issue, where the 14 unpack instructions per float4 would cost more than the bytes.
+constexpr float kFix24 = 8388607.0f;
+// (a 3-vector type is padded to 16 bytes: the 12-byte lane stride is applied by hand, the access itself is one
+// global_store / global_load_dwordx3)
+typedef unsigned u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+template <int T>
+DEV void store_act24(float* dst, Lane ln, const Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    unsigned q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = (unsigned)(int)__builtin_rintf(a.v[t][r] * kFix24);
+    u32x3 d = {__builtin_amdgcn_perm(q[1], q[0], 0x04020100u),   // q0.b0 q0.b1 q0.b2 q1.b0
+               __builtin_amdgcn_perm(q[2], q[1], 0x05040201u),   // q1.b1 q1.b2 q2.b0 q2.b1
+               __builtin_amdgcn_perm(q[3], q[2], 0x06050402u)};  // q2.b2 q3.b0 q3.b1 q3.b2
+    __builtin_nontemporal_store(d, reinterpret_cast<u32x3*>(reinterpret_cast<char*>(dst) + (t * 64 + ln.lane) * 12));
+  }
+}
+template <int T>
+DEV void load_act24(const float* src, Lane ln, Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const u32x3 d = __builtin_nontemporal_load(reinterpret_cast<const u32x3*>(reinterpret_cast<const char*>(src) + (t * 64 + ln.lane) * 12));
+    const int q0 = (int)(d[0] << 8) >> 8;
+    const int q1 = (int)(__builtin_amdgcn_alignbit(d[1], d[0], 24) << 8) >> 8;
+    const int q2 = (int)(__builtin_amdgcn_alignbit(d[2], d[1], 16) << 8) >> 8;
+    const int q3 = (int)d[2] >> 8;
+    a.v[t] = f32x4{(float)q0, (float)q1, (float)q2, (float)q3} * (1.0f / kFix24);
+  }
+}
+
 // 16 per-rollout values spread over the 4 lanes of a rollout (lane (i,q) holds values 4q..4q+3) ->
 // all 16 in every lane, through the wave's LDS scratch (in-order per wave, no barrier needed).
 DEV void gather16(float* scr, Lane ln, f32x4 mine, float (&out)[16]) {
@@ -2011,8 +2046,9 @@ struct OdeModel {
     return to4_rep<T>(L + oW4r, ln, tp.a3) + b4;
   }
 
-  // floats one wave stashes per step: a2, a3 (a1 is recomputed from (x,u))
-  static constexpr int STASH = 2 * T * 256;
+  // floats one wave stashes per step: a2, a3 as 24-bit fixed point (store_act24; a1 is recomputed from (x,u))
+  static constexpr int VEC24 = T * 192;
+  static constexpr int STASH = 2 * VEC24;
 
   template <bool WANT_H, bool ST = false>
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, f32x4 uv, float& Hval, float* stash = nullptr) {
@@ -2021,8 +2057,8 @@ struct OdeModel {
     if (WANT_H) Hval = 0.f;
     f32x4 dx = fwd(L, ln, x, u, tp);
     if (ST) {
-      store_act<T>(stash, ln, tp.a2);
-      store_act<T>(stash + T * 256, ln, tp.a3);
+      store_act24<T>(stash, ln, tp.a2);
+      store_act24<T>(stash + VEC24, ln, tp.a3);
     }
     return dx;
   }
@@ -2035,8 +2071,8 @@ struct OdeModel {
     float ubar;
     Tape tp;
     if (ST) {
-      load_act<T>(stash + T * 256, ln, tp.a3);  // the backward sweep meets a3 first
-      load_act<T>(stash, ln, tp.a2);
+      load_act24<T>(stash + VEC24, ln, tp.a3);  // the backward sweep meets a3 first
+      load_act24<T>(stash, ln, tp.a2);
       keep_lds_reads_local();
       layer1(L, ln, x, u, tp.a1);
     } else {

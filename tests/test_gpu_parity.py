@@ -39,7 +39,7 @@ def npy(t):
 
 
 TRAJ_ATOL = {"phnn_cartpole": 1e-5, "canonical_cartpole": 1e-5, "phnn_pendulum": 5e-5, "odefunc_pendulum": 5e-5,
-             "odefunc_cartpole": 1e-5, "phnn_cartpole_odd": 1e-5}
+             "odefunc_cartpole": 1e-5, "phnn_cartpole_odd": 1e-5, "phnn_cartpole_trained": 1e-5}
 
 
 def assert_rollout_close(cost, traj, gu, gx0, ref_cost, ref_traj, ref_gu, ref_gx0, traj_atol=1e-5):
@@ -207,7 +207,9 @@ def test_stash_and_recompute_modes_agree(bundle, integ):
         eng.use_stash = True
     assert np.array_equal(c1, c2)
     gmax = np.abs(g2).max(axis=(1, 2), keepdims=True)
-    assert np.all(np.abs(g1 - g2) <= 1e-6 * gmax) and np.allclose(x1, x2, rtol=1e-5, atol=1e-6 * np.abs(x2).max())
+    # ODEFunc keeps its tape as 24-bit fixed point (absolute error 6e-8 per tanh output): agreement to 5e-6 instead of 1e-6
+    tol = 5e-6 if name.startswith("odefunc") else 1e-6
+    assert np.all(np.abs(g1 - g2) <= tol * gmax) and np.allclose(x1, x2, rtol=1e-5, atol=tol * np.abs(x2).max())
     ref = m64.rollout(x0, U, cost, integ, float(g["dt"]), nthreads=8)
     assert np.all(np.abs(g2 - ref["grad_u"]) <= 1e-4 * np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True))
     assert np.all(np.abs(g1 - ref["grad_u"]) <= 1e-4 * np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True))
