@@ -242,13 +242,22 @@ DEV unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: round-to-nearest
 // tools/probe_coexec.hip shows why it cannot be more: on this part an MFMA stream of one wave (bf16 or f32, either
 // shape) hides only ~20 % of its time under the partner wave's VALU work -- matrix and vector time nearly add.
 DEV void matrix_phase_begin() {
-#ifndef PHNN_NO_SETPRIO
+#if !defined(PHNN_NO_SETPRIO) && !defined(PHNN_STATIC_PRIO)
   __builtin_amdgcn_s_setprio(0);
 #endif
 }
 DEV void matrix_phase_end() {
-#ifndef PHNN_NO_SETPRIO
+#if !defined(PHNN_NO_SETPRIO) && !defined(PHNN_STATIC_PRIO)
   __builtin_amdgcn_s_setprio(2);
+#endif
+}
+// experiment (PHNN_STATIC_PRIO): no per-phase flips; the second-dispatched half of the workgroup (waves 4-7, the
+// arbitration losers by age) runs at priority 1 throughout.  Measured (round 3, same box, 3 x 100 steps): per-phase
+// flips 29.26, static 29.35, no s_setprio at all 29.34 M/s -- all within 0.3 %; the flips stay (they were worth 2 % on
+// round 1's kernels and cost nothing now)
+DEV void static_prio(int wave) {
+#ifdef PHNN_STATIC_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
 }
 
@@ -727,6 +736,8 @@ struct HTape {
   Act<HID / 16> a1, a2, q1;  // activations, and q1 = W2^T g2 (before the (1-a1^2) factor)
 };
 
+// (Measured, round 3, not kept: streaming a2 out right behind its tanh, so that its stores drain underneath the transposed
+// product instead of queueing with q1's: K1 +0.8 %, K2 unchanged.)
 template <int HID, bool WANT_H, int MM = MM_F32, int SITE = kInHFwd>
 DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hval) {
   using Y = LayH2<HID, MM>;
@@ -2281,6 +2292,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   constexpr int N = M::N;
   stage_image<M::IMG>(lds, p.img);
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  static_prio(wave);
   Lane ln;
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
@@ -2340,6 +2352,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   constexpr int N = M::N;
   stage_image<M::IMG>(lds, p.img);
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  static_prio(wave);
   Lane ln;
   ln.lane = threadIdx.x & 63;
   ln.i = ln.lane & 15;
