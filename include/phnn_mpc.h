@@ -58,10 +58,13 @@ typedef enum { PHNN_INTEG_EULER = 0, PHNN_INTEG_RK4 = 1 } phnn_integrator; /* sr
  *                                         M^-1 = inverse of that 2x2 matrix.   q_dim = 2 (state_dim 4) only. */
 typedef enum { PHNN_MASS_CARTPOLE = 0, PHNN_MASS_CONSTANT = 1, PHNN_MASS_DIAGONAL = 2, PHNN_MASS_FULL = 3 } phnn_mass_type;
 
-/* Activation of every MLP in the model (src/NN.py:6-40 takes any nn.Module class; src/pHNN.py:41 resolves it by
- * name).  Only Tanh has kernels -- the one every shipped config selects; anything else is refused by phnn_create so
- * that a checkpoint trained with another activation (same keys, same shapes) cannot be run as a Tanh network. */
-typedef enum { PHNN_ACT_TANH = 0, PHNN_ACT_OTHER = 1 } phnn_activation;
+/* Activation of every MLP in the model (src/NN.py:6-40 takes any nn.Module class -- its default is nn.SiLU;
+ * src/pHNN.py:41 resolves it by name; src/baseline_node.py:49-58 offers relu / tanh / elu / gelu).  Tanh is what every
+ * shipped config selects and what the fast kernels implement; SiLU and ReLU run on the all-f32 kernels (their
+ * activations are unbounded, so the f16 / bf16 split products do not apply; rollouts and VJPs only, no weight-gradient
+ * kernels); anything else (OTHER) is refused by phnn_create so that a checkpoint trained with another activation (same
+ * keys, same shapes) cannot be run as the wrong network.  One activation per model: all its MLPs must agree. */
+typedef enum { PHNN_ACT_TANH = 0, PHNN_ACT_OTHER = 1, PHNN_ACT_SILU = 2, PHNN_ACT_RELU = 3 } phnn_activation;
 
 /* How the hidden x hidden products are evaluated.  DEFAULT: f16x2 for 128-wide models, f32 for
  * narrower ones (f16x2 on the 64-wide trained pendulum model is known to exceed the stated tolerance in long
@@ -93,7 +96,7 @@ typedef struct {
   phnn_mlp_shape h_net; /* H_net, or the ODEFunc network */
   phnn_mlp_shape r_net; /* PHNN only */
   phnn_mlp_shape g_net; /* PHNN with fixed_G == 0 only */
-  int32_t activation;   /* phnn_activation; must be PHNN_ACT_TANH */
+  int32_t activation;   /* phnn_activation: TANH, SILU or RELU */
   int32_t mass_type;    /* CANONICAL only: phnn_mass_type */
   phnn_mlp_shape m_net; /* CANONICAL with mass_type DIAGONAL / FULL: hidden layers of M_net.mlp */
 } phnn_desc;

@@ -45,6 +45,7 @@ class RolloutEngine:
             raise PhnnError("RolloutEngine needs a GPU device (cuda:N); there is no CPU path")
         if not torch.cuda.is_available():
             raise PhnnError("no GPU visible to torch; the rollout engine has no CPU fallback")
+        self.activation = activation
         self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind, activation=activation)
         self.n, self.m, self.kind = self.desc.n, self.desc.m, self.desc.kind
         self.layout = weights.blob_layout(state_dict, kind=self.kind)  # [(state_dict key, offset, shape)] of the blob
@@ -79,7 +80,7 @@ class RolloutEngine:
 
     def update_weights(self, state_dict):
         """Re-pack and re-upload the weights of the same architecture (after an optimizer step / load_state_dict)."""
-        desc, blob = weights.pack_state_dict(state_dict, kind=self.kind, activation="tanh")
+        desc, blob = weights.pack_state_dict(state_dict, kind=self.kind, activation=self.activation)
         if blob.size != self.blob.size:
             raise PhnnError("update_weights: the state_dict describes another architecture")
         self.blob = blob

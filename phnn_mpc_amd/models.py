@@ -189,6 +189,8 @@ class _EngineBacked(nn.Module):
                 return mod.activation_name
         return "tanh"
 
+    SUPPORTED_ACTIVATIONS = ("Tanh", "SiLU", "ReLU")  # Tanh: every kernel family; SiLU / ReLU: the all-f32 rollout kernels
+
     def set_engine(self, engine):
         """Attach an already built engine (tests use this to run the host logic without a GPU)."""
         self._engine = engine
@@ -215,10 +217,13 @@ class _EngineBacked(nn.Module):
         for name, mod in self.named_modules():
             if isinstance(mod, MassMatrixNetwork) and mod.activation_name != "Tanh":
                 raise NotImplementedError(f"{name}: the M_net.mlp kernel implements Tanh, got {mod.activation_name}")
-            if isinstance(mod, MLP) and (not mod.plain or mod.activation_name != "Tanh"):
+            if isinstance(mod, MLP) and (not mod.plain or mod.activation_name not in self.SUPPORTED_ACTIVATIONS):
                 raise NotImplementedError(
-                    f"{name}: the rollout kernels implement Linear/Tanh MLPs (bias, no LayerNorm/Dropout), the only "
-                    f"variant the shipped configs select; got activation={mod.activation_name}, plain={mod.plain}")
+                    f"{name}: the rollout kernels implement Linear + Tanh / SiLU / ReLU MLPs (bias, no LayerNorm/Dropout); "
+                    f"got activation={mod.activation_name}, plain={mod.plain}")
+        acts = {mod.activation_name for mod in self.modules() if isinstance(mod, MLP)}
+        if len(acts) > 1:
+            raise NotImplementedError(f"the kernels take ONE activation per model; this one mixes {sorted(acts)}")
 
     @staticmethod
     def _flatten(x):  # src/pHNN.py:58-66
@@ -402,7 +407,8 @@ class ODEFunc(_EngineBacked):
         acts = {"relu": nn.ReLU, "tanh": nn.Tanh, "elu": nn.ELU, "gelu": nn.GELU}
         if activation not in acts:
             raise ValueError(f"Unknown activation: {activation}")
-        self._plain = activation == "tanh" and not layer_norm
+        self._plain = activation in ("tanh", "relu") and not layer_norm
+        self._act = activation
         mods, prev = [], state_dim + action_dim
         for h in hidden_sizes:
             mods.append(nn.Linear(prev, h))
@@ -419,7 +425,10 @@ class ODEFunc(_EngineBacked):
 
     def _check_supported(self):
         if not self._plain:
-            raise NotImplementedError("the ODEFunc kernel implements tanh without LayerNorm (the default)")
+            raise NotImplementedError("the ODEFunc kernels implement tanh (default) and relu, without LayerNorm")
+
+    def _activation_name(self):
+        return self._act
 
     def forward(self, t, state):
         if self.current_action is None:

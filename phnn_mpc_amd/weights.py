@@ -82,10 +82,11 @@ def detect_kind(sd):
 
 
 def _activation_code(activation):
-    """'tanh' / 'Tanh' / 'nn.Tanh' / torch.nn.Tanh -> PHNN_ACT_TANH; anything else -> PHNN_ACT_OTHER (refused by
-    phnn_create).  The state_dict itself does not say which activation a checkpoint was trained with."""
+    """'tanh' / 'Tanh' / 'nn.Tanh' / torch.nn.Tanh -> PHNN_ACT_TANH, likewise SiLU and ReLU; anything else ->
+    PHNN_ACT_OTHER (refused by phnn_create).  The state_dict itself does not say which activation a checkpoint was
+    trained with."""
     name = activation if isinstance(activation, str) else getattr(activation, "__name__", str(activation))
-    return _capi.ACT_TANH if name.split(".")[-1].lower() == "tanh" else _capi.ACT_OTHER
+    return _capi.ACTIVATIONS.get(name.split(".")[-1].lower(), _capi.ACT_OTHER)
 
 
 def pack_state_dict(sd, kind=None, state_dim=None, input_dim=None, activation="tanh"):

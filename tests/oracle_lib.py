@@ -50,8 +50,8 @@ def _ptr(a):
 class OracleModel:
     """One reference model restated on the CPU, in float32 ('f32') or float64 ('f64')."""
 
-    def __init__(self, state_dict, precision="f64", kind=None):
-        self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind)
+    def __init__(self, state_dict, precision="f64", kind=None, activation="tanh"):
+        self.desc, self.blob = weights.pack_state_dict(state_dict, kind=kind, activation=activation)
         self.suf = precision
         self.dtype = np.float64 if precision == "f64" else np.float32
         self.n, self.m = self.desc.n, self.desc.m
@@ -194,6 +194,8 @@ def load_m2_golden():
 
 
 M2_MODELS = ["phnn_m2_fix", "phnn_m2_gnet", "canonical_m2"]
+# models with other activations than Tanh (tests/golden/make_golden_act.py): name -> activation
+ACT_MODELS = {"phnn_silu": "silu", "phnn_relu": "relu", "canonical_silu": "silu", "odefunc_relu": "relu"}
 
 
 def load_named_golden(fname):
