@@ -729,17 +729,147 @@ DEV void store_rec_scaled(float* dst, Lane ln, const Act<T>& a, float s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Activations other than Tanh (src/NN.py:13 defaults to nn.SiLU; src/pHNN.py:41 resolves any nn.* by name;
+// src/baseline_node.py:49-58 offers relu): SiLU and ReLU on the all-f32 kernels.  Their outputs are unbounded, so the
+// f16 / bf16 split products (which rely on |tanh| <= 1) do not apply, and phi' / phi'' need the PRE-activation: the
+// tapes of these variants keep z where the Tanh kernels keep a = tanh(z).  Values = phnn_activation.
+// ------------------------------------------------------------------------------------------------
+constexpr int ACT_TANH = 0, ACT_SILU = 2, ACT_RELU = 3;
+
+template <int ACT>
+DEV void act_eval(float z, float& a, float& d1) {  // phi(z), phi'(z)
+  if (ACT == ACT_RELU) {
+    a = fmaxf(z, 0.f);
+    d1 = z > 0.f ? 1.0f : 0.0f;  // torch: subgradient 0 at 0
+  } else {  // SiLU: z s, s (1 + z (1 - s)) with s = sigmoid(z)
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+    a = z * s;
+    d1 = __builtin_fmaf(a, 1.0f - s, s);
+  }
+}
+template <int ACT>
+DEV float act_d2(float z) {  // phi''(z)
+  if (ACT == ACT_RELU) return 0.0f;
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+  return s * (1.0f - s) * __builtin_fmaf(z, 1.0f - 2.0f * s, 2.0f);
+}
+template <int ACT, int T>
+DEV void act_of(const Act<T>& z, Act<T>& a) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float av, d;
+      act_eval<ACT>(z.v[t][r], av, d);
+      a.v[t][r] = av;
+    }
+}
+template <int ACT, int T>
+DEV void mul_d1(Act<T>& g, const Act<T>& z) {  // g *= phi'(z)
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a, d;
+      act_eval<ACT>(z.v[t][r], a, d);
+      g.v[t][r] *= d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // H_net: value, gradient and Hessian-vector product (src/pHNN.py:72-73, src/pHNN_canonical.py:208-215)
 // ------------------------------------------------------------------------------------------------
 template <int HID>
 struct HTape {
-  Act<HID / 16> a1, a2, q1;  // activations, and q1 = W2^T g2 (before the (1-a1^2) factor)
+  Act<HID / 16> a1, a2, q1;  // activations (SiLU / ReLU variants: PRE-activations z1, z2), and q1 = W2^T g2
 };
+
+// generic-activation H_net on the all-f32 image (packed WITHOUT the folded tanh constant: S = Sb = k1 = 1)
+template <int HID, bool WANT_H, int ACT>
+DEV f32x4 hnet_grad_g(const float* L, Lane ln, f32x4 x, HTape<HID>& tp, float& Hval) {
+  using Y = LayH2<HID, MM_F32>;
+  constexpr int T = Y::T;
+  load_vec<T>(tp.a1, L + Y::oB1, ln);
+  in_layer<T>(tp.a1, L + Y::oW1f, ln, sel4(x, ln.q));  // z1
+  {
+    Act<T> a;
+    act_of<ACT, T>(tp.a1, a);
+    load_vec<T>(tp.a2, L + Y::oB2, ln);
+    sq_fwd<T, T>(tp.a2, L + Y::oW2, ln, a);  // z2
+  }
+  Act<T> g;
+  float s = 0.f;
+  keep_lds_reads_local();
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * t + 4 * ln.q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a, d;
+      act_eval<ACT>(tp.a2.v[t][r], a, d);
+      if (WANT_H) s = __builtin_fmaf(w3[r], a, s);
+      g.v[t][r] = w3[r] * d;  // g2 = w3 phi'(z2)
+    }
+  }
+  if (WANT_H) Hval = reduce_q(s) + L[Y::oB3];
+  zero_act<T>(tp.q1);
+  sq_bwd<T, T>(tp.q1, L + Y::oW2, ln, g);
+#pragma unroll
+  for (int t = 0; t < T; ++t) g.v[t] = tp.q1.v[t];
+  mul_d1<ACT, T>(g, tp.a1);  // g1 = q1 phi'(z1)
+  return to4_rep<T>(L + Y::oW1T, ln, g);
+}
+template <int HID, int ACT>
+DEV void hnet_layer1_g(const float* L, Lane ln, f32x4 x, Act<HID / 16>& z1) {
+  using Y = LayH2<HID, MM_F32>;
+  load_vec<Y::T>(z1, L + Y::oB1, ln);
+  in_layer<Y::T>(z1, L + Y::oW1f, ln, sel4(x, ln.q));
+}
+// Hv = (d^2 H / dx^2) v:  zd1 = W1 v, ad1 = phi'(z1) zd1, zd2 = W2 ad1, gd2 = w3 phi''(z2) zd2, qd1 = W2^T gd2,
+// gd1 = qd1 phi'(z1) + q1 phi''(z1) zd1, Hv = W1^T gd1   (oracle/phnn_oracle.c: hnet_hvp).  Consumes tp.q1.
+template <int HID, int ACT>
+DEV f32x4 hnet_hvp_g(const float* L, Lane ln, HTape<HID>& tp, f32x4 v) {
+  using Y = LayH2<HID, MM_F32>;
+  constexpr int T = Y::T;
+  Act<T> ad1, w;
+  zero_act<T>(ad1);
+  in_layer<T>(ad1, L + Y::oW1f, ln, sel4(v, ln.q));  // zd1
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z = tp.a1.v[t][r], zd = ad1.v[t][r];
+      float a, d;
+      act_eval<ACT>(z, a, d);
+      tp.q1.v[t][r] = tp.q1.v[t][r] * (act_d2<ACT>(z) * zd);  // second term of gd1
+      ad1.v[t][r] = d * zd;
+    }
+  zero_act<T>(w);
+  sq_fwd<T, T>(w, L + Y::oW2, ln, ad1);  // zd2
+  keep_lds_reads_local();
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3 + 16 * t + 4 * ln.q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w.v[t][r] = w3[r] * (act_d2<ACT>(tp.a2.v[t][r]) * w.v[t][r]);  // gd2
+  }
+  Act<T> qd;
+  zero_act<T>(qd);
+  sq_bwd<T, T>(qd, L + Y::oW2, ln, w);
+  mul_d1<ACT, T>(qd, tp.a1);
+#pragma unroll
+  for (int t = 0; t < T; ++t) qd.v[t] = qd.v[t] + tp.q1.v[t];
+  return to4_rep<T>(L + Y::oW1T, ln, qd);
+}
 
 // (Measured, round 3, not kept: streaming a2 out right behind its tanh, so that its stores drain underneath the transposed
 // product instead of queueing with q1's: K1 +0.8 %, K2 unchanged.)
-template <int HID, bool WANT_H, int MM = MM_F32, int SITE = kInHFwd>
+template <int HID, bool WANT_H, int MM = MM_F32, int SITE = kInHFwd, int ACT = ACT_TANH>
 DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hval) {
+  if constexpr (ACT != ACT_TANH) {
+    static_assert(MM == MM_F32, "SiLU / ReLU run on the all-f32 kernels");
+    return hnet_grad_g<HID, WANT_H, ACT>(L, ln, z, tp, Hval);
+  }
   using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(tp.a1, L + Y::oB1, ln);
@@ -806,8 +936,9 @@ DEV f32x4 hnet_grad(const float* L, Lane ln, f32x4 z, HTape<HID>& tp, float& Hva
 
 // first hidden activation of H_net from its input: cheap (one k-step, 8 f32 MFMAs + tanh) -- K2 recomputes it
 // instead of reading it from the stash, which cuts the stash traffic by a third
-template <int HID, int MM>
+template <int HID, int MM, int ACT = ACT_TANH>
 DEV void hnet_layer1(const float* L, Lane ln, f32x4 z, Act<HID / 16>& a1) {
+  if constexpr (ACT != ACT_TANH) return hnet_layer1_g<HID, ACT>(L, ln, z, a1);
   using Y = LayH2<HID, MM>;
   load_vec<Y::T>(a1, L + Y::oB1, ln);
   in_layer_mm<Y::T, MM, kInHRecomp>(a1, L, Y::oW1f, Y::oW1h, ln, z);
@@ -816,8 +947,12 @@ DEV void hnet_layer1(const float* L, Lane ln, f32x4 z, Act<HID / 16>& a1) {
 
 // Hv = (d^2 H / dz^2) v : forward-over-reverse through the kept tape (a1, a2, q1).  Consumes the tape
 // (q1 is overwritten) to keep the live register set at five activation vectors.
-template <int HID, int MM = MM_F32, bool WG = false>
+template <int HID, int MM = MM_F32, bool WG = false, int ACT = ACT_TANH>
 DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v, float* rec = nullptr) {
+  if constexpr (ACT != ACT_TANH) {
+    static_assert(!WG, "weight-gradient kernels exist for Tanh models only");
+    return hnet_hvp_g<HID, ACT>(L, ln, tp, v);
+  }
   using Y = LayH2<HID, MM>;
   constexpr int T = Y::T;
   float unscale = 1.0f;
@@ -949,21 +1084,32 @@ DEV void load_rf(const float* src, Lane ln, float (&rf)[16]) {
   }
 }
 // hidden layer only (the adjoint with a tape: the outputs come from there)
-template <int HID, int MM = MM_F32, int SITE = kInHNet1>
+template <int HID, int MM = MM_F32, int SITE = kInHNet1, int ACT = ACT_TANH>
 DEV void h1_hidden(const float* L, Lane ln, f32x4 x, Act<HID / 16>& h) {
   using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(h, L + Y::oC1, ln);
   in_layer_mm<T, MM, SITE>(h, L, Y::oV1f, Y::oV1h, ln, x);
-  tanh_act_pre<T>(h);
+  if constexpr (ACT == ACT_TANH) tanh_act_pre<T>(h);  // SiLU / ReLU: h keeps the PRE-activation (h1_bwd needs phi'(z))
 }
 
-template <int HID, int MM = MM_F32, int SITE = kInHNet1>
+template <int HID, int MM = MM_F32, int SITE = kInHNet1, int ACT = ACT_TANH>
 DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, float (&out)[16], float* rf_stash = nullptr) {
   using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
   load_vec<T>(h, L + Y::oC1, ln);
   in_layer_mm<T, MM, SITE>(h, L, Y::oV1f, Y::oV1h, ln, x);
+  if constexpr (ACT != ACT_TANH) {  // h stays z; the output layer takes phi(z)
+    static_assert(MM == MM_F32, "SiLU / ReLU run on the all-f32 kernels");
+    Act<T> a;
+    act_of<ACT, T>(h, a);
+    Act<1> og;
+    og.v[0] = *reinterpret_cast<const f32x4*>(L + Y::oC2 + 4 * ln.q);
+    sq_fwd<1, T>(og, L + Y::oV2, ln, a);
+    if (rf_stash) store_rf(rf_stash, ln, og.v[0]);
+    gather16(scr, ln, og.v[0], out);
+    return;
+  }
   tanh_act_pre<T>(h);
   Act<1> o;
   if (Y::HF) {
@@ -982,11 +1128,22 @@ DEV void h1_fwd(const float* L, float* scr, Lane ln, f32x4 x, Act<HID / 16>& h, 
 // MM_F16X2: obar is normalised per rollout by a power of two (the map is linear), split hi/lo and STACKED along the
 // K = 32 of one MFMA: k-slots 0..15 carry hi(obar), 16..31 lo(obar), against [V2^T hi | V2^T hi]; a second MFMA adds
 // V2^T lo x hi(obar).  Two 16-cycle MFMAs per tile of hidden units instead of four 32-cycle f32 ones.
-template <int HID, int MM = MM_F32, bool WG = false>
+template <int HID, int MM = MM_F32, bool WG = false, int ACT = ACT_TANH>
 DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&obar)[16], float* rec = nullptr) {
   using Y = LayH1<HID, MM>;
   constexpr int T = Y::T;
   Act<T> hb;
+  if constexpr (ACT != ACT_TANH) {  // h holds the pre-activation
+    static_assert(MM == MM_F32 && !WG, "SiLU / ReLU: all-f32 kernels, no weight-gradient records");
+    Act<1> ob;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      ob.v[0][r] = ln.q == 0 ? obar[r] : (ln.q == 1 ? obar[4 + r] : (ln.q == 2 ? obar[8 + r] : obar[12 + r]));
+    zero_act<T>(hb);
+    sq_bwd<T, 1>(hb, L + Y::oV2, ln, ob);
+    mul_d1<ACT, T>(hb, h);
+    return to4_rep<T>(L + Y::oV1T, ln, hb);
+  }
   float unscale = 1.0f;
   if (Y::HF) {
     f16x8 b1, b2;
@@ -1017,9 +1174,9 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
 // ------------------------------------------------------------------------------------------------
 // Model: pHNN (src/pHNN.py:52-100)
 // ------------------------------------------------------------------------------------------------
-template <int N_, int HID_, bool FIXG_, int MM_ = MM_F32, int MI_ = 1>
+template <int N_, int HID_, bool FIXG_, int MM_ = MM_F32, int MI_ = 1, int ACT_ = ACT_TANH>
 struct PhnnModel {
-  static constexpr int N = N_, HID = HID_, T = HID / 16, MM = MM_, MI = MI_;  // MI = input_dim m (controls per step)
+  static constexpr int N = N_, HID = HID_, T = HID / 16, MM = MM_, MI = MI_, ACT = ACT_;  // MI = input_dim m (controls per step)
   static constexpr bool FIXG = FIXG_, SPLIT = false;
   static_assert(N_ * MI_ <= 16 && MI_ <= 4, "G_net output n*m <= 16, m <= 4");
   static constexpr int SCR = kScrFloats;  // per-wave LDS scratch (exchange of the 16 R_net / G_net outputs)
@@ -1040,7 +1197,7 @@ struct PhnnModel {
   DEV static f32x4 f(const float* L, float* scr, Lane ln, f32x4 x, f32x4 u, float& Hval, float* stash = nullptr) {
     keep_lds_reads_local();
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, x, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, MM, kInHFwd, ACT>(L + oH, ln, x, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a2);
       store_act<T>(stash + T * 256, ln, tp.q1);
@@ -1048,7 +1205,7 @@ struct PhnnModel {
     }
     Act<T> hR;
     float rf[16];
-    h1_fwd<HID, MM>(L + oR, scr, ln, x, hR, rf, ST ? stash + oStashRf : nullptr);
+    h1_fwd<HID, MM, kInHNet1, ACT>(L + oR, scr, ln, x, hR, rf, ST ? stash + oStashRf : nullptr);
     float G[N * MI];  // G(x) row-major (N, MI): G_fixed buffer or G_net(x).view(n, m)  (src/pHNN.py:86-92)
     if (FIXG) {
 #pragma unroll
@@ -1056,7 +1213,7 @@ struct PhnnModel {
     } else {
       Act<T> hG;
       float gf[16];
-      h1_fwd<HID, MM>(L + oGn, scr, ln, x, hG, gf);
+      h1_fwd<HID, MM, kInHNet1, ACT>(L + oGn, scr, ln, x, hG, gf);
 #pragma unroll
       for (int i = 0; i < N * MI; ++i) G[i] = gf[i];
     }
@@ -1119,9 +1276,9 @@ struct PhnnModel {
       load_rf(stash + oStashRf, ln, rf);
       load_act<T>(stash, ln, tp.a2);
       load_act<T>(stash + T * 256, ln, tp.q1);
-      hnet_layer1<HID, MM>(L + oH, ln, x, tp.a1);
+      hnet_layer1<HID, MM, ACT>(L + oH, ln, x, tp.a1);
     } else {
-      dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, x, tp, Hdummy);
+      dH = hnet_grad<HID, false, MM, kInHRecomp, ACT>(L + oH, ln, x, tp, Hdummy);
     }
     if (WG && !ST) {  // with the tapes of K1 the reduction reads a2, q1 from there (their record slots stay unwritten)
       store_rec<T>(rec, ln, tp.a2);
@@ -1132,9 +1289,9 @@ struct PhnnModel {
     {
       Act<T> hR;
       if (ST) {  // R_net's outputs came with the tape: only its hidden layer is re-evaluated
-        h1_hidden<HID, MM, kInHNet1Adj>(L + oR, ln, x, hR);
+        h1_hidden<HID, MM, kInHNet1Adj, ACT>(L + oR, ln, x, hR);
       } else {
-        h1_fwd<HID, MM, kInHNet1Adj>(L + oR, scr, ln, x, hR, rf);
+        h1_fwd<HID, MM, kInHNet1Adj, ACT>(L + oR, scr, ln, x, hR, rf);
       }
 #pragma unroll
       for (int i = 0; i < N; ++i)
@@ -1163,7 +1320,7 @@ struct PhnnModel {
           float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
           rbar[i * N + j] = (sij + sji) * 0.5f;
         }
-      xb += h1_bwd<HID, MM, WG && RECHB>(L + oR, ln, hR, rbar, WG && RECHB ? rec + 4 * Rec::VEC : nullptr);
+      xb += h1_bwd<HID, MM, WG && RECHB, ACT>(L + oR, ln, hR, rbar, WG && RECHB ? rec + 4 * Rec::VEC : nullptr);
       if (WG && ln.q == 0) {
         f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
 #pragma unroll
@@ -1179,7 +1336,7 @@ struct PhnnModel {
     } else {
       Act<T> hG;
       float gf[16], gbar[16];
-      h1_fwd<HID, MM, kInHNet1Adj>(L + oGn, scr, ln, x, hG, gf);
+      h1_fwd<HID, MM, kInHNet1Adj, ACT>(L + oGn, scr, ln, x, hG, gf);
 #pragma unroll
       for (int k = 0; k < 16; ++k) gbar[k] = 0.f;
 #pragma unroll
@@ -1189,7 +1346,7 @@ struct PhnnModel {
           ubar[k] = __builtin_fmaf(gf[i * MI + k], lam[i], ubar[k]);
           gbar[i * MI + k] = lam[i] * u[k];
         }
-      xb += h1_bwd<HID, MM, WG && RECHB>(L + oGn, ln, hG, gbar, WG && RECHB ? rec + 5 * Rec::VEC : nullptr);
+      xb += h1_bwd<HID, MM, WG && RECHB, ACT>(L + oGn, ln, hG, gbar, WG && RECHB ? rec + 5 * Rec::VEC : nullptr);
     }
     // v = A^T lam, A = Jeff - S S^T
     f32x4 v = splat4(0.f);
@@ -1211,7 +1368,7 @@ struct PhnnModel {
       sm[8] = u;
       sm[9] = f32x4{Hbar, 0.f, 0.f, 0.f};
     }
-    xbar = xb + hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
+    xbar = xb + hnet_hvp<HID, MM, WG, ACT>(L + oH, ln, tp, v, rec);
     if (WG) xbar = xbar + Hbar * dH;
   }
 };
@@ -1305,9 +1462,9 @@ DEV f32x4 mass_outputs_bar(f32x4 o, const float (&Mb)[4]) {
 // Model: canonical pHNN with the cart-pole mass matrix (src/pHNN_canonical.py:172-273,
 // src/mass_matrix.py:270-362, src/coordinate_transforms.py:20-130)
 // ------------------------------------------------------------------------------------------------
-template <int HID_, int MM_ = MM_F32, int MI_ = 1, int MT_ = MASS_CARTPOLE>
+template <int HID_, int MM_ = MM_F32, int MI_ = 1, int MT_ = MASS_CARTPOLE, int ACT_ = ACT_TANH>
 struct CanonModel {
-  static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_, MI = MI_, MT = MT_;  // MT: mass matrix type
+  static constexpr int N = 4, HID = HID_, T = HID / 16, MM = MM_, MI = MI_, MT = MT_, ACT = ACT_;  // MT: mass matrix type
   static constexpr bool SPLIT = false;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int oH = 0;
@@ -1352,7 +1509,7 @@ struct CanonModel {
       mass_eval(L, ln, y, m, w, mt);
       f32x4 z = {y[0], y[1], m[0] * y[2] + m[1] * y[3], m[1] * y[2] + m[2] * y[3]};
       HTape<HID> tp;
-      f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, z, tp, Hval);
+      f32x4 dH = hnet_grad<HID, WANT_H, MM, kInHFwd, ACT>(L + oH, ln, z, tp, Hval);
       if (ST) {
         store_act<T>(stash, ln, tp.a2);
         store_act<T>(stash + T * 256, ln, tp.q1);
@@ -1368,7 +1525,7 @@ struct CanonModel {
     float bc = b * cs;
     f32x4 z = {y[0], y[1], a * y[2] + bc * y[3], bc * y[2] + c * y[3]};
     HTape<HID> tp;
-    f32x4 dH = hnet_grad<HID, WANT_H, MM>(L + oH, ln, z, tp, Hval);
+    f32x4 dH = hnet_grad<HID, WANT_H, MM, kInHFwd, ACT>(L + oH, ln, z, tp, Hval);
     if (ST) {
       store_act<T>(stash, ln, tp.a2);
       store_act<T>(stash + T * 256, ln, tp.q1);
@@ -1406,9 +1563,9 @@ struct CanonModel {
         dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
         load_act<T>(stash, ln, tp.a2);
         load_act<T>(stash + T * 256, ln, tp.q1);
-        hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
+        hnet_layer1<HID, MM, ACT>(L + oH, ln, z, tp.a1);
       } else {
-        dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, z, tp, Hdummy);
+        dH = hnet_grad<HID, false, MM, kInHRecomp, ACT>(L + oH, ln, z, tp, Hdummy);
       }
       const float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
       const float dp0 = (-dH[0] - Rd2 * dH[2]) + Base_Gu(L, 2, u);
@@ -1433,7 +1590,7 @@ struct CanonModel {
           sm[9] = f32x4{Hbar, 0.f, 0.f, 0.f};
         }
       }
-      f32x4 zb = hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
+      f32x4 zb = hnet_hvp<HID, MM, WG, ACT>(L + oH, ln, tp, v, rec);
       if (WG) zb = zb + Hbar * dH;
       zb[2] += pb0;
       zb[3] += pb1;
@@ -1476,9 +1633,9 @@ struct CanonModel {
       dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
       load_act<T>(stash, ln, tp.a2);
       load_act<T>(stash + T * 256, ln, tp.q1);
-      hnet_layer1<HID, MM>(L + oH, ln, z, tp.a1);
+      hnet_layer1<HID, MM, ACT>(L + oH, ln, z, tp.a1);
     } else {
-      dH = hnet_grad<HID, false, MM, kInHRecomp>(L + oH, ln, z, tp, Hdummy);
+      dH = hnet_grad<HID, false, MM, kInHRecomp, ACT>(L + oH, ln, z, tp, Hdummy);
     }
     float Rd2 = L[oC + 6], Rd3 = L[oC + 7];
     float dp0 = (-dH[0] - Rd2 * dH[2]) + Base_Gu(L, 2, u);
@@ -1510,7 +1667,7 @@ struct CanonModel {
         sm[9] = f32x4{Hbar, 0.f, 0.f, 0.f};
       }
     }
-    f32x4 zb = hnet_hvp<HID, MM, WG>(L + oH, ln, tp, v, rec);
+    f32x4 zb = hnet_hvp<HID, MM, WG, ACT>(L + oH, ln, tp, v, rec);
     if (WG) zb = zb + Hbar * dH;
     zb[2] += pb0;
     zb[3] += pb1;
@@ -1980,9 +2137,10 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
 // ------------------------------------------------------------------------------------------------
 // Model: ODEFunc MLP [x,u] -> HID -> HID -> HID -> n  (src/baseline_node.py:60-116), n + m <= 4
 // ------------------------------------------------------------------------------------------------
-template <int N_, int HID_, int MM_ = MM_F32>
+template <int N_, int HID_, int MM_ = MM_F32, int ACT_ = ACT_TANH>
 struct OdeModel {
-  static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8, MM = MM_, MI = 1;
+  static constexpr int N = N_, HID = HID_, T = HID / 16, LD = HID + 4, LR = HID + 8, MM = MM_, MI = 1, ACT = ACT_;
+  static_assert(ACT_ == ACT_TANH || MM_ == MM_F32, "SiLU / ReLU run on the all-f32 kernels");
   static constexpr bool SPLIT = false;
   static constexpr int SCR = 0;  // no per-wave LDS scratch needed
   static constexpr int WF = MM == MM_F16X2 ? HfImg<HID>::FLOATS : HID * LD;  // one hidden x hidden image
@@ -2007,7 +2165,7 @@ struct OdeModel {
   static_assert(N <= 4, "state dimension up to 4");
 
   struct Tape {
-    Act<T> a1, a2, a3;
+    Act<T> a1, a2, a3;  // activations; SiLU / ReLU variants: the PRE-activations z1, z2, z3
   };
 
   DEV static void layer1(const float* L, Lane ln, f32x4 x, float u, Act<T>& a1) {
@@ -2016,12 +2174,18 @@ struct OdeModel {
     load_vec<T>(a1, L + oB1, ln);
     in_layer<T>(a1, L + oW1f, ln, sel4(in, ln.q));
     if (WIDE) in_layer<T>(a1, L + oW1fu, ln, ln.q == 0 ? u : 0.f);
-    tanh_act<T>(a1);
+    if constexpr (ACT == ACT_TANH) tanh_act<T>(a1);
   }
 
   // hidden -> hidden layer: o = tanh(b + W a)
   DEV static void hidden(const float* L, Lane ln, int oW, int oB, float c, const Act<T>& a, Act<T>& o) {
     load_vec<T>(o, L + oB, ln);
+    if constexpr (ACT != ACT_TANH) {  // a holds z of the previous layer; o becomes z of this one
+      Act<T> act;
+      act_of<ACT, T>(a, act);
+      sq_fwd<T, T>(o, L + oW, ln, act);
+      return;
+    }
     if (MM == MM_F16X2) {
       Split2<T> sp;
       split_act_h<T>(a, sp);
@@ -2054,11 +2218,17 @@ struct OdeModel {
     hidden(L, ln, oW2, oB2, L[oSC + 0], tp.a1, tp.a2);
     hidden(L, ln, oW3, oB3, L[oSC + 1], tp.a2, tp.a3);
     f32x4 b4 = *reinterpret_cast<const f32x4*>(L + oB4);
+    if constexpr (ACT != ACT_TANH) {
+      Act<T> act;
+      act_of<ACT, T>(tp.a3, act);
+      return to4_rep<T>(L + oW4r, ln, act) + b4;
+    }
     return to4_rep<T>(L + oW4r, ln, tp.a3) + b4;
   }
 
   // floats one wave stashes per step: a2, a3 as 24-bit fixed point (store_act24; a1 is recomputed from (x,u))
-  static constexpr int VEC24 = T * 192;
+  // (SiLU / ReLU: the pre-activations z2, z3 are unbounded: plain float32, T x 256 floats each)
+  static constexpr int VEC24 = ACT == ACT_TANH ? T * 192 : T * 256;
   static constexpr int STASH = 2 * VEC24;
 
   template <bool WANT_H, bool ST = false>
@@ -2068,8 +2238,13 @@ struct OdeModel {
     if (WANT_H) Hval = 0.f;
     f32x4 dx = fwd(L, ln, x, u, tp);
     if (ST) {
-      store_act24<T>(stash, ln, tp.a2);
-      store_act24<T>(stash + VEC24, ln, tp.a3);
+      if constexpr (ACT == ACT_TANH) {
+        store_act24<T>(stash, ln, tp.a2);
+        store_act24<T>(stash + VEC24, ln, tp.a3);
+      } else {
+        store_act<T>(stash, ln, tp.a2);
+        store_act<T>(stash + VEC24, ln, tp.a3);
+      }
     }
     return dx;
   }
@@ -2082,8 +2257,13 @@ struct OdeModel {
     float ubar;
     Tape tp;
     if (ST) {
-      load_act24<T>(stash + VEC24, ln, tp.a3);  // the backward sweep meets a3 first
-      load_act24<T>(stash, ln, tp.a2);
+      if constexpr (ACT == ACT_TANH) {
+        load_act24<T>(stash + VEC24, ln, tp.a3);  // the backward sweep meets a3 first
+        load_act24<T>(stash, ln, tp.a2);
+      } else {
+        load_act<T>(stash + VEC24, ln, tp.a3);
+        load_act<T>(stash, ln, tp.a2);
+      }
       keep_lds_reads_local();
       layer1(L, ln, x, u, tp.a1);
     } else {
@@ -2101,14 +2281,22 @@ struct OdeModel {
     Act<T> d, e;
     zero_act<T>(d);
     in_layer<T>(d, L + oW4f, ln, sel4(lam, ln.q));
+    if constexpr (ACT != ACT_TANH) {
+      mul_d1<ACT, T>(d, tp.a3);
+      hidden_T(L, ln, oW3, d, e);
+      mul_d1<ACT, T>(e, tp.a2);
+      hidden_T(L, ln, oW2, e, d);
+      mul_d1<ACT, T>(d, tp.a1);
+    } else {
 #pragma unroll
-    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * dtanh(tp.a3.v[t]);
-    hidden_T(L, ln, oW3, d, e);
+      for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * dtanh(tp.a3.v[t]);
+      hidden_T(L, ln, oW3, d, e);
 #pragma unroll
-    for (int t = 0; t < T; ++t) e.v[t] = e.v[t] * dtanh(tp.a2.v[t]);
-    hidden_T(L, ln, oW2, e, d);
+      for (int t = 0; t < T; ++t) e.v[t] = e.v[t] * dtanh(tp.a2.v[t]);
+      hidden_T(L, ln, oW2, e, d);
 #pragma unroll
-    for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * dtanh(tp.a1.v[t]);
+      for (int t = 0; t < T; ++t) d.v[t] = d.v[t] * dtanh(tp.a1.v[t]);
+    }
     f32x4 inb = to4_rep<T>(L + oW1T, ln, d);
     if (MM == MM_F16X2) inb = inb * unscale;
     if (WIDE) {

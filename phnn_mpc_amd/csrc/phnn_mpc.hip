@@ -137,7 +137,19 @@ int matmul_mode(const phnn_options& o, int hid) {
 int pick_variant(const phnn_desc* d, const phnn_options& opt, std::string* why) {
   char buf[256];
   if (d->activation != PHNN_ACT_TANH) {
-    *why = "activation: only Tanh MLPs have kernels (src/NN.py takes any activation; every shipped config selects Tanh)";
+    // SiLU / ReLU: whole-tile all-f32 kernels of the cart-pole sized models (narrower nets are zero-padded: phi(0) = 0)
+    const bool silu = d->activation == PHNN_ACT_SILU, relu = d->activation == PHNN_ACT_RELU;
+    if ((silu || relu) && d->m == 1 && opt.matmul_mode != PHNN_MATMUL_BF16X3 && opt.matmul_mode != PHNN_MATMUL_F16X2) {
+      if (d->kind == PHNN_MODEL_PHNN && d->n == 4 && d->fixed_G && same_hidden(d->h_net, 2, 128) && same_hidden(d->r_net, 1, 128))
+        return silu ? V_PHNN_4_128_FIX_SILU : V_PHNN_4_128_FIX_RELU;
+      if (d->kind == PHNN_MODEL_CANONICAL && d->mass_type == PHNN_MASS_CARTPOLE && d->n == 4 && same_hidden(d->h_net, 2, 128))
+        return silu ? V_CANON_128_SILU : V_CANON_128_RELU;
+      if (d->kind == PHNN_MODEL_ODEFUNC && relu && same_hidden(d->h_net, 3, 128) && (d->n == 2 || d->n == 4))
+        return d->n == 2 ? V_ODE_2_128_RELU : V_ODE_4_128_RELU;
+    }
+    *why = "activation: Tanh has every kernel family; SiLU / ReLU have all-f32 rollout kernels for the pHNN (n = 4, fixed G) and "
+           "the canonical cart-pole pHNN (hidden widths up to 128), ReLU also for ODEFunc (n = 2 | 4, three hidden layers up to "
+           "128), m = 1, matmul mode default / f32; other activations (src/NN.py takes any nn.Module) have none";
     return V_NONE;
   }
   {
@@ -332,7 +344,8 @@ float pack_f16x2(float* dstf, const float* W) {
   return S;
 }
 
-template <int HID, int MM>
+// FOLD: Tanh models only -- SiLU / ReLU images carry the plain weights (S = Sb = k1 = 1)
+template <int HID, int MM, bool FOLD = true>
 const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes W1,b1,W2,b2,W3,b3 from p
   using Y = LayH2<HID, MM>;
   const float* W1 = p; p += (size_t)HID * nin;
@@ -343,7 +356,7 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   const float* b3 = p; p += 1;
   // 128-wide: tanh's 2 log2(e) is folded into the weights and biases in front of each tanh (kPreScaled in the
   // kernels); every later use of those pre-activations' scale goes through S and k1 below.
-  const float k1 = kPreScaled<HID / 16> ? 2.8853900817779268f : 1.0f;
+  const float k1 = (FOLD && kPreScaled<HID / 16>) ? 2.8853900817779268f : 1.0f;
   std::vector<float> W1s((size_t)HID * nin), W2s((size_t)HID * HID);
   for (size_t k = 0; k < W1s.size(); ++k) W1s[k] = W1[k] * k1;
   for (size_t k = 0; k < W2s.size(); ++k) W2s[k] = W2[k] * k1;
@@ -387,7 +400,7 @@ const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes 
   return p;
 }
 
-template <int HID, int MM>
+template <int HID, int MM, bool FOLD = true>
 const float* pack_h1(float* dst, const float* p, int nin, int nout) {  // R_net / G_net
   using Y = LayH1<HID, MM>;
   const float* V1 = p; p += (size_t)HID * nin;
@@ -420,7 +433,7 @@ const float* pack_h1(float* dst, const float* p, int nin, int nout) {  // R_net 
     pack_rows(dst + Y::oV2, V2, nout, HID, Y::LD);
     dst[Y::oSc] = 1.0f;
   }
-  const float k1 = kPreScaled<HID / 16> ? 2.8853900817779268f : 1.0f;  // folded tanh constant (see pack_h2)
+  const float k1 = (FOLD && kPreScaled<HID / 16>) ? 2.8853900817779268f : 1.0f;  // folded tanh constant (see pack_h2)
   std::vector<float> V1s((size_t)HID * nin);
   for (size_t k = 0; k < V1s.size(); ++k) V1s[k] = V1[k] * k1;
   pack_in_frag<HID>(dst + Y::oV1f, V1s.data(), nin);
@@ -438,9 +451,10 @@ void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
   const float* J = p; p += N * N;
   const float* G = nullptr;
   if (d->fixed_G) { G = p; p += N * M::MI; }
-  p = pack_h1<HID, M::MM>(img.data() + M::oR, p, N, N * N);
-  p = pack_h2<HID, M::MM>(img.data() + M::oH, p, N);
-  if (!d->fixed_G) p = pack_h1<HID, M::MM>(img.data() + M::oGn, p, N, N * M::MI);
+  constexpr bool FOLD = M::ACT == ACT_TANH;
+  p = pack_h1<HID, M::MM, FOLD>(img.data() + M::oR, p, N, N * N);
+  p = pack_h2<HID, M::MM, FOLD>(img.data() + M::oH, p, N);
+  if (!d->fixed_G) p = pack_h1<HID, M::MM, FOLD>(img.data() + M::oGn, p, N, N * M::MI);
   for (int i = 0; i < N; ++i)
     for (int j = 0; j < N; ++j) img[M::oJ + i * N + j] = J[i * N + j] - J[j * N + i];  // src/pHNN.py:83, no 1/2
   if (G)
@@ -489,6 +503,7 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
   else if (d->kind == PHNN_MODEL_CANONICAL) W = mx <= 64 ? 64 : 128;
   else W = (d->n == 2 && mx <= 64) ? 64 : 128;
   if (d->m > 1) W = 128;  // the m = 2 kernels exist at width 128 only
+  if (d->activation != PHNN_ACT_TANH) W = 128;  // so do the SiLU / ReLU ones
   if (d->kind == PHNN_MODEL_CANONICAL && d->mass_type != PHNN_MASS_CARTPOLE) W = 128;  // so do the MassMatrixNetwork ones
   if (mx > W || mx < 1) {
     char buf[160];
@@ -627,7 +642,7 @@ void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
     pack_in_frag_T<64>(dm + LayM::oWoTf, Wo, nout);
     pack_cols_as_rows(dm + LayM::oW1T, W1, 64, 2, LayM::LR);
   }
-  p = pack_h2<HID, M::MM>(img.data() + M::oH, p, 4);
+  p = pack_h2<HID, M::MM, M::ACT == ACT_TANH>(img.data() + M::oH, p, 4);
   for (int i = 0; i < 4; ++i) c[4 + i] = softplus_host(Rd[i]) + 1e-4f;  // src/pHNN_canonical.py:162
   // softplus'(raw) = sigmoid(raw) (threshold 20 as torch.nn.functional.softplus): the weight-gradient kernels need it
   for (int i = 0; i < 4; ++i) c[8 + i] = Rd[i] > 20.f ? 1.0f : (float)(1.0 / (1.0 + std::exp(-(double)Rd[i])));
@@ -705,6 +720,12 @@ void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float*
     case V_PHNN_4_128_FIX_H_M2: pack_phnn<M_PHNN_4_128_FIX_H_M2>(img, d, blob); break;
     case V_PHNN_4_128_GNET_H_M2: pack_phnn<M_PHNN_4_128_GNET_H_M2>(img, d, blob); break;
     case V_CANON_128_H_M2: pack_canon<M_CANON_128_H_M2>(img, d, blob); break;
+    case V_PHNN_4_128_FIX_SILU: pack_phnn<M_PHNN_4_128_FIX_SILU>(img, d, blob); break;
+    case V_PHNN_4_128_FIX_RELU: pack_phnn<M_PHNN_4_128_FIX_RELU>(img, d, blob); break;
+    case V_CANON_128_SILU: pack_canon<M_CANON_128_SILU>(img, d, blob); break;
+    case V_CANON_128_RELU: pack_canon<M_CANON_128_RELU>(img, d, blob); break;
+    case V_ODE_2_128_RELU: pack_ode<M_ODE_2_128_RELU>(img, d, blob); break;
+    case V_ODE_4_128_RELU: pack_ode<M_ODE_4_128_RELU>(img, d, blob); break;
     case V_CANON_128_H_MCONST: pack_canon<M_CANON_128_H_MCONST>(img, d, blob); break;
     case V_CANON_128_H_MDIAG: pack_canon<M_CANON_128_H_MDIAG>(img, d, blob); break;
     case V_CANON_128_H_MFULL: pack_canon<M_CANON_128_H_MFULL>(img, d, blob); break;

@@ -36,6 +36,12 @@ enum Variant {
   V_CANON_128_H_MCONST,  // canonical pHNN with MassMatrixNetwork 'constant' / 'diagonal' / 'full' (src/mass_matrix.py:15-216)
   V_CANON_128_H_MDIAG,
   V_CANON_128_H_MFULL,
+  V_PHNN_4_128_FIX_SILU,  // other activations than Tanh (src/NN.py:13 default nn.SiLU; src/baseline_node.py:49-50 relu): all-f32 kernels
+  V_PHNN_4_128_FIX_RELU,
+  V_CANON_128_SILU,
+  V_CANON_128_RELU,
+  V_ODE_2_128_RELU,
+  V_ODE_4_128_RELU,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -68,6 +74,12 @@ using M_CANON_128_H_M2 = CanonModel<128, MM_F16X2, 2>;
 using M_CANON_128_H_MCONST = CanonModel<128, MM_F16X2, 1, MASS_CONSTANT>;
 using M_CANON_128_H_MDIAG = CanonModel<128, MM_F16X2, 1, MASS_DIAGONAL>;
 using M_CANON_128_H_MFULL = CanonModel<128, MM_F16X2, 1, MASS_FULL>;
+using M_PHNN_4_128_FIX_SILU = PhnnModel<4, 128, true, MM_F32, 1, ACT_SILU>;
+using M_PHNN_4_128_FIX_RELU = PhnnModel<4, 128, true, MM_F32, 1, ACT_RELU>;
+using M_CANON_128_SILU = CanonModel<128, MM_F32, 1, MASS_CARTPOLE, ACT_SILU>;
+using M_CANON_128_RELU = CanonModel<128, MM_F32, 1, MASS_CARTPOLE, ACT_RELU>;
+using M_ODE_2_128_RELU = OdeModel<2, 128, MM_F32, ACT_RELU>;
+using M_ODE_4_128_RELU = OdeModel<4, 128, MM_F32, ACT_RELU>;
 
 struct GradSet {
   void (*grad[2])(RollParams);     // Euler, RK4: recompute the tape
@@ -139,4 +151,10 @@ hipError_t phnn_wgrad_finish(const float* slab, int rows, int PP, const int* map
   X(V_CANON_128_H_M2, M_CANON_128_H_M2, "canonical<m=2,hid=128,f16x2>") \
   X(V_CANON_128_H_MCONST, M_CANON_128_H_MCONST, "canonical<hid=128,f16x2,mass=constant>") \
   X(V_CANON_128_H_MDIAG, M_CANON_128_H_MDIAG, "canonical<hid=128,f16x2,mass=diagonal>") \
-  X(V_CANON_128_H_MFULL, M_CANON_128_H_MFULL, "canonical<hid=128,f16x2,mass=full>")
+  X(V_CANON_128_H_MFULL, M_CANON_128_H_MFULL, "canonical<hid=128,f16x2,mass=full>") \
+  X(V_PHNN_4_128_FIX_SILU, M_PHNN_4_128_FIX_SILU, "phnn<n=4,hid=128,fixedG,silu>") \
+  X(V_PHNN_4_128_FIX_RELU, M_PHNN_4_128_FIX_RELU, "phnn<n=4,hid=128,fixedG,relu>") \
+  X(V_CANON_128_SILU, M_CANON_128_SILU, "canonical<hid=128,silu>") \
+  X(V_CANON_128_RELU, M_CANON_128_RELU, "canonical<hid=128,relu>") \
+  X(V_ODE_2_128_RELU, M_ODE_2_128_RELU, "odefunc<n=2,hid=128,relu>") \
+  X(V_ODE_4_128_RELU, M_ODE_4_128_RELU, "odefunc<n=4,hid=128,relu>")
