@@ -44,6 +44,14 @@ for tag in ("wgrad", "rk4"):  # per-kernel stats of the training pass (f4) and o
     if m:
         shutil.copy(max(m, key=os.path.getmtime), os.path.join(dst, f"{prefix}_{tag}_kernel_stats.csv"))
         shutil.copy(os.path.join(src, f"{tag}_probe.txt"), os.path.join(dst, f"{prefix}_{tag}_probe.txt"))
-for a, b in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"), ("other_configs.jsonl", "_other_configs.jsonl")):
-    shutil.copy(os.path.join(src, a), os.path.join(dst, prefix + b))
+for mode in ("bf16x3", "f32"):  # kernel stats of the 24-bit-exact product modes (their roofline.frac is checkable from these)
+    m = glob.glob(os.path.join(src, f"trace_{mode}/**/*kernel_stats.csv"), recursive=True)
+    if m:
+        shutil.copy(max(m, key=os.path.getmtime), os.path.join(dst, f"{prefix}_{mode}_kernel_stats.csv"))
+        shutil.copy(os.path.join(src, f"bench_under_rocprof_{mode}.json"), os.path.join(dst, f"{prefix}_bench_under_rocprof_{mode}.json"))
+for a, b in (("bench.json", "_bench.json"), ("bench_under_rocprof.json", "_bench_under_rocprof.json"), ("other_configs.jsonl", "_other_configs.jsonl"),
+             ("bench_config4.json", "_bench_config4.json"), ("latency_probe.txt", "_latency_probe.txt"),
+             ("train_step_probe.txt", "_train_step_probe.txt"), ("parity_margin_trained.txt", "_parity_margin_trained.txt")):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, prefix + b))
 print(json.dumps(out, indent=1))
