@@ -24,7 +24,10 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int kTileB = 16;       // rollouts per wave
-constexpr int kMaxWaves = 8;     // waves per workgroup (2 per SIMD)
+#ifndef PHNN_KMAXWAVES
+#define PHNN_KMAXWAVES 8
+#endif
+constexpr int kMaxWaves = PHNN_KMAXWAVES;  // waves per workgroup (8 = 2 per SIMD; 12 = 3 per SIMD is an experiment: DESIGN.md section 9)
 constexpr int kScrFloats = 16 * 20;  // per-wave LDS scratch: 16 rollouts x (16 + 4 pad) floats
 
 struct Lane {
