@@ -414,3 +414,24 @@ def test_small_batch_latency_report(torch):
               rep[("c1", "never")], rep[("c1", "always")], rep[("c2euler", "never")], rep[("c2euler", "always")],
               rep[("c2rk4", "never")], rep[("c2rk4", "always")]))
     assert rep[("c1", "always")] < rep[("c1", "never")] and rep[("c2euler", "always")] < rep[("c2euler", "never")]
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal(torch):
+    """The N > 1 flow of bench.py on real kernels: `python bench.py --gpus 2` launches its own two ranks, both on this
+    one GPU with the gloo rehearsal backend (RCCL refuses two ranks per device; the driver's runs use nccl, one GPU per
+    rank).  The line must report two ranks, weak scaling over 2 x batch, the real backend in its labels, a
+    strong-scaling object for the ragged split, and a roofline from the HIP events of rank 0."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PHNN_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8192", "--steps", "5", "--warmup", "2",
+                        "--global-batch", "9001", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16384 and line["config"]["collective_backend"] == "gloo"
+    assert "RCCL" not in line["config"]["workload"] and line["metric"].endswith("batch=8192")
+    assert line["value"] > 1e6 and line["roofline"]["frac"] > 0 and line["strong_scaling"]["global_batch"] == 9001
+    assert "rehearsal" not in line  # real kernels: only the collective backend is the rehearsal one
