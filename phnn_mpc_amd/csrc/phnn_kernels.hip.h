@@ -485,6 +485,38 @@ DEV void sq_fwd_h(Act<T>& o, const float* Wimg, Lane ln, const Split2<T>& in) {
   keep_lds_reads_local();
   matrix_phase_begin();
   const char* base = reinterpret_cast<const char*>(Wimg) + ln.i * (I::RS * 2) + ln.q * 16;
+#ifndef PHNN_NO_PREFETCH_FRAGS
+  // The fragments of group g + 1 are requested before the MFMAs of group g (double buffer, pinned by sched_barrier: left
+  // to itself the scheduler sinks every fragment load to just before its first use, and every six-MFMA group then waits
+  // out a full LDS round trip).  Round 3, same box: K2 1.218 -> 1.185 ms at two waves per SIMD, 1.46 -> 1.36 ms at one;
+  // K1 unchanged.  Two groups ahead costs K2 its registers (spills, +7 %).  Same MFMA order per accumulator: bitwise
+  // the same results.
+  {
+    constexpr int PD = 1, NB = PD + 1;
+    f16x8 a[NB][2][2];
+    auto loadg = [&](int g, f16x8 (&dst)[2][2]) {
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          dst[gg][p] = *reinterpret_cast<const f16x8*>(base + p * I::PART + (n0 + gg) * 16 * (I::RS * 2) + s * 64);
+    };
+    constexpr int NG = (T / 2) * (T / 2);
+#pragma unroll
+    for (int g = 0; g < PD && g < NG; ++g) loadg(g, a[g % NB]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + PD < NG) loadg(g + PD, a[(g + PD) % NB]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+      mfma3x2(o.v[n0], o.v[n0 + 1], a[g % NB], in.h[s], in.l[s]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    matrix_phase_end();
+    return;
+  }
+#endif
 #pragma unroll
   for (int n0 = 0; n0 < T; n0 += 2) {
 #pragma unroll
@@ -510,6 +542,39 @@ DEV void sq_bwd_h(Act<T>& o, const float* Wimg, Lane ln, const Split2<T>& in) {
   typedef char __attribute__((address_space(3))) * lds_cp;
   const int a4 = (ln.lane & 15) >> 2, pp = ln.lane & 3;
   lds_cp base = (lds_cp) const_cast<char*>(reinterpret_cast<const char*>(Wimg)) + (4 * ln.q + a4) * (I::RS * 2) + 16 * pp;
+#ifndef PHNN_NO_PREFETCH_FRAGS
+  {
+    f16x8 a[2][2][2];
+    auto loadg = [&](int g, f16x8 (&dst)[2][2]) {
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int nt = n0 + gg;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          lds_cp off = base + p * I::PART + 32 * s * (I::RS * 2) + (64 * (nt >> 1) + 8 * (nt & 1));
+          f16x4 lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)off));
+          f16x4 hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(off + 16 * (I::RS * 2))));
+          dst[gg][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+    };
+    constexpr int NG = (T / 2) * (T / 2);
+    constexpr int PD = 1, NB = PD + 1;
+#pragma unroll
+    for (int g = 0; g < PD && g < NG; ++g) loadg(g, a[g % NB]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + PD < NG) loadg(g + PD, a[(g + PD) % NB]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+      mfma3x2(o.v[n0], o.v[n0 + 1], a[g % NB], in.h[s], in.l[s]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    matrix_phase_end();
+    return;
+  }
+#endif
 #pragma unroll
   for (int n0 = 0; n0 < T; n0 += 2) {
 #pragma unroll
@@ -1279,7 +1344,8 @@ struct PhnnModel {
       load_rf(stash + oStashRf, ln, rf);
       load_act<T>(stash, ln, tp.a2);
       load_act<T>(stash + T * 256, ln, tp.q1);
-      hnet_layer1<HID, MM, ACT>(L + oH, ln, x, tp.a1);
+      // (a1 is recomputed further down, right before the Hessian-vector product: it is not live through the R_net part,
+      // which is where this kernel's register peak sits.  K2 1.179 -> 1.154 ms.  Issuing a2's loads later too: no change.)
     } else {
       dH = hnet_grad<HID, false, MM, kInHRecomp, ACT>(L + oH, ln, x, tp, Hdummy);
     }
@@ -1371,6 +1437,7 @@ struct PhnnModel {
       sm[8] = u;
       sm[9] = f32x4{Hbar, 0.f, 0.f, 0.f};
     }
+    if (ST) hnet_layer1<HID, MM, ACT>(L + oH, ln, x, tp.a1);
     xbar = xb + hnet_hvp<HID, MM, WG, ACT>(L + oH, ln, tp, v, rec);
     if (WG) xbar = xbar + Hbar * dH;
   }
@@ -1755,6 +1822,8 @@ DEV void sq_bwd_h_w(ActW& o, const float* Wimg, Lane ln, const Split2<8>& in) {
   typedef char __attribute__((address_space(3))) * lds_cp;
   const int a4 = (ln.lane & 15) >> 2, pp = ln.lane & 3;
   lds_cp base = (lds_cp) const_cast<char*>(reinterpret_cast<const char*>(Wimg)) + (4 * ln.q + a4) * (I::RS * 2) + 16 * pp + 64 * ln.w;
+  // (requesting all four k-steps' fragments up front -- one wave per SIMD here, nothing else covers the LDS round trips --
+  // was measured in round 3: single-plant solve 3.68 -> 3.74 ms, no gain; the step is bound by its barriers)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     f16x8 a[2][2];
