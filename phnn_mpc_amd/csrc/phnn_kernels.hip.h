@@ -461,8 +461,10 @@ DEV void in_layer_h(Act<T>& o, const float* Wh, Lane ln, f16x8 xf) {
 // layer of R_net / G_net inside the adjoint (kInHNet1Adj): with it the headline adjoint kernel spills 120 B per lane
 // (measured: every site f16 = K1 -3.8 %, K2 +7 %; this mask = K1 -2.5 %, K2 -0.6 %).
 constexpr int kInHFwd = 1, kInHRecomp = 2, kInHHvp = 4, kInHNet1 = 8, kInHNet1Adj = 16;
+// (Round 3: with a1 recomputed late the adjoint has the registers for the f16 form at kInHNet1Adj too: K2 -0.9 %, no
+// spill in the headline kernel; the mask is now every site.)
 #ifndef PHNN_INH_MASK
-#define PHNN_INH_MASK (kInHFwd | kInHRecomp | kInHHvp | kInHNet1)
+#define PHNN_INH_MASK (kInHFwd | kInHRecomp | kInHHvp | kInHNet1 | kInHNet1Adj)
 #endif
 template <int T, int MM, int SITE>
 DEV void in_layer_mm(Act<T>& o, const float* Lnet, int oF, int oFh, Lane ln, f32x4 x, int tile0 = 0) {
