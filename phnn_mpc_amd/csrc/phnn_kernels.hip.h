@@ -1241,6 +1241,37 @@ DEV f32x4 h1_bwd(const float* L, Lane ln, const Act<HID / 16>& h, const float (&
   return Y::HF ? xb * unscale : xb;
 }
 
+// S = sym(R_raw) = (R_raw + R_raw^T) / 2 (src/pHNN.py:77-80) from the 16 outputs of R_net: the diagonal is exact
+// ((x + x) / 2 == x) and each off-diagonal pair is formed once.
+template <int N>
+DEV void sym_from_rf(const float (&rf)[16], float (&S)[N][N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    S[i][i] = rf[i * N + i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) S[i][j] = S[j][i] = (rf[i * N + j] + rf[j * N + i]) * 0.5f;
+  }
+}
+// Cotangent of R_raw from the dissipation term -S S^T dH:  Sbar = -(lam (S^T dH)^T + dH (S^T lam)^T),
+// R_raw_bar = (Sbar + Sbar^T) / 2 -- symmetric: the upper triangle is formed once and mirrored, the diagonal is -m_ii.
+// Shared by the whole-tile and the split-tile adjoint (bitwise the same by construction).
+template <int N>
+DEV void rbar_from(f32x4 lam, f32x4 dH, const float (&Stl)[N], const float (&StdH)[N], float (&rbar)[16]) {
+  float m[N][N];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) rbar[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) m[i][j] = __builtin_fmaf(lam[i], StdH[j], dH[i] * Stl[j]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    rbar[i * N + i] = -m[i][i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) rbar[i * N + j] = rbar[j * N + i] = (m[i][j] + m[j][i]) * -0.5f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Model: pHNN (src/pHNN.py:52-100)
 // ------------------------------------------------------------------------------------------------
@@ -1292,10 +1323,7 @@ struct PhnnModel {
 
   DEV static f32x4 combine(const float* L, const float (&rf)[16], f32x4 dH, const float (&G)[N * MI], f32x4 u) {
     float S[N][N], StdH[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-      for (int j = 0; j < N; ++j) S[i][j] = (rf[i * N + j] + rf[j * N + i]) * 0.5f;
+    sym_from_rf<N>(rf, S);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       float a = 0.f;
@@ -1364,10 +1392,7 @@ struct PhnnModel {
       } else {
         h1_fwd<HID, MM, kInHNet1Adj, ACT>(L + oR, scr, ln, x, hR, rf);
       }
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) S[i][j] = (rf[i * N + j] + rf[j * N + i]) * 0.5f;
+      sym_from_rf<N>(rf, S);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         float a = 0.f, c = 0.f;
@@ -1381,16 +1406,7 @@ struct PhnnModel {
       }
       // dissipation term: Sbar = -(lam (S^T dH)^T + dH (S^T lam)^T), R_raw_bar = (Sbar + Sbar^T)/2
       float rbar[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) rbar[k] = 0.f;
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          float sij = -(lam[i] * StdH[j] + dH[i] * Stl[j]);
-          float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
-          rbar[i * N + j] = (sij + sji) * 0.5f;
-        }
+      rbar_from<N>(lam, dH, Stl, StdH, rbar);
       xb += h1_bwd<HID, MM, WG && RECHB, ACT>(L + oR, ln, hR, rbar, WG && RECHB ? rec + 4 * Rec::VEC : nullptr);
       if (WG && ln.q == 0) {
         f32x4* sm = reinterpret_cast<f32x4*>(rec + Rec::oSmall + ln.i * kRecSmall);
@@ -2047,10 +2063,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
       dH = xch_sum_partials(ln.xch + kXP0, ln);
     }
     float S[N][N], Stl[N], StdH[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-      for (int j = 0; j < N; ++j) S[i][j] = (rf[i * N + j] + rf[j * N + i]) * 0.5f;
+    sym_from_rf<N>(rf, S);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       float a = 0.f, c = 0.f;
@@ -2063,16 +2076,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
       StdH[k] = c;
     }
     float rbar[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) rbar[k] = 0.f;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        float sij = -(lam[i] * StdH[j] + dH[i] * Stl[j]);
-        float sji = -(lam[j] * StdH[i] + dH[j] * Stl[i]);
-        rbar[i * N + j] = (sij + sji) * 0.5f;
-      }
+    rbar_from<N>(lam, dH, Stl, StdH, rbar);
     // transposed output layer of R_net on the own tiles, then the wave's partial of V1^T (.)
     float unscaleR;
     f32x4 PR;
@@ -2387,6 +2391,11 @@ struct OdeModel {
 // ------------------------------------------------------------------------------------------------
 // stage cost (src/mpc_controller.py:75-114, src/mpc_controller_canonical.py:91-120)
 // ------------------------------------------------------------------------------------------------
+// The soft state barrier (src/mpc_controller.py:96-107; off in every shipped configuration) sits behind a REAL branch:
+// left to if-conversion its ~25 vector instructions ran in every step of every rollout and were masked out afterwards.
+// The empty asm has side effects as far as the compiler knows, so the block cannot be speculated.
+DEV void no_speculation() { asm volatile("" ::: "memory"); }
+
 template <int N>
 DEV float state_cost(const phnn_cost& c, f32x4 x) {
   float e[N], cost = 0.f;
@@ -2400,6 +2409,7 @@ DEV float state_cost(const phnn_cost& c, f32x4 x) {
     cost = __builtin_fmaf(s, e[j], cost);
   }
   if (c.has_x_min) {
+    no_speculation();
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -2409,6 +2419,7 @@ DEV float state_cost(const phnn_cost& c, f32x4 x) {
     cost = __builtin_fmaf(c.barrier_weight, s, cost);
   }
   if (c.has_x_max) {
+    no_speculation();
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -2420,8 +2431,9 @@ DEV float state_cost(const phnn_cost& c, f32x4 x) {
   return cost;
 }
 
+// Qs = Q + Q^T from the host (RollParams::Qs; the same float32 sum the kernel used to form per step)
 template <int N>
-DEV f32x4 state_cost_grad(const phnn_cost& c, f32x4 x) {
+DEV f32x4 state_cost_grad(const phnn_cost& c, const float (&Qs)[16], f32x4 x) {
   float e[N];
   f32x4 g = splat4(0.f);
 #pragma unroll
@@ -2430,10 +2442,18 @@ DEV f32x4 state_cost_grad(const phnn_cost& c, f32x4 x) {
   for (int i = 0; i < N; ++i) {
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < N; ++j) s = __builtin_fmaf(c.Q[i * N + j] + c.Q[j * N + i], e[j], s);
-    if (c.has_x_min) s = __builtin_fmaf(-2.0f * c.barrier_weight, fmaxf(c.x_min[i] - x[i], 0.f), s);
-    if (c.has_x_max) s = __builtin_fmaf(2.0f * c.barrier_weight, fmaxf(x[i] - c.x_max[i], 0.f), s);
+    for (int j = 0; j < N; ++j) s = __builtin_fmaf(Qs[i * N + j], e[j], s);
     g[i] = s;
+  }
+  if (c.has_x_min) {
+    no_speculation();
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = __builtin_fmaf(-2.0f * c.barrier_weight, fmaxf(c.x_min[i] - x[i], 0.f), g[i]);
+  }
+  if (c.has_x_max) {
+    no_speculation();
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = __builtin_fmaf(2.0f * c.barrier_weight, fmaxf(x[i] - c.x_max[i], 0.f), g[i]);
   }
   return g;
 }
@@ -2461,6 +2481,7 @@ struct RollParams {
   int H;
   float dt, half_dt, sixth_dt;
   phnn_cost c;
+  float Qs[16];        // Q + Q^T (row-major n x n), formed on the host in float32: the adjoint used to rebuild it every step
 };
 
 struct PointParams {
@@ -2637,7 +2658,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   const float* db = p.dx_bar ? p.dx_bar + (b * p.H) * N : nullptr;
   // a padding lane (rollout index beyond the batch) must not contribute to the weight gradient: its cotangents are zeroed
   const float live = valid ? 1.0f : 0.0f;
-  f32x4 lam = cb * state_cost_grad<N>(p.c, load_state<N>(tr + (long long)p.H * N));
+  f32x4 lam = cb * state_cost_grad<N>(p.c, p.Qs, load_state<N>(tr + (long long)p.H * N));
   if (tb) lam = lam + load_state<N>(tb + (long long)p.H * N);
   if (WG) lam = lam * live;
   constexpr int STAGES = INTEG == PHNN_INTEG_EULER ? 1 : 4;
@@ -2705,7 +2726,7 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
       uraw = load_u<MI>(up, t);
       u = p.no_cost ? uraw : clamp_u4<MI>(p.c, uraw);
     }
-    lam = lam + cb * state_cost_grad<N>(p.c, x);
+    lam = lam + cb * state_cost_grad<N>(p.c, p.Qs, x);
     if (tb) lam = lam + load_state<N>(tb + (long long)t * N) * (WG ? live : 1.0f);
 #pragma unroll
     for (int k = 0; k < MI; ++k) {

@@ -1065,6 +1065,9 @@ static int fill_roll(phnn_handle* h, RollParams* p, const float* x0, const float
   p->half_dt = (float)(dtd / 2);
   p->sixth_dt = (float)(dtd / 6.0);
   p->c = *cost;
+  const int n = h->desc.n;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) p->Qs[i * n + j] = cost->Q[i * n + j] + cost->Q[j * n + i];  // float32 sum, as the kernel formed it
   return PHNN_OK;
 }
 
