@@ -623,7 +623,13 @@ DEV f32x4 to4_group(const float* Wt_group, Lane ln, const f32x4* in_tiles) {  //
   return o0 + o1;
 }
 
+// Sums over the four lanes of a rollout (lane = 16 q + i): (v_q + v_{q^1}) first, then across the wave halves -- the
+// association of v += xor16; v += xor32.  v_permlane16_swap / v_permlane32_swap exchange rows between TWO registers, so a
+// copy of the value swapped against itself leaves the two partners in the pair; all in the vector ALU, no LDS round trip
+// (ds_bpermute) and no lgkmcnt wait.  (The __builtin_amdgcn_permlane*_swap builtins of this compiler return the first
+// result twice when both operands hold the same value -- tools/probe_permlane.hip -- hence the assembly.)
 DEV f32x4 to4_kslots(f32x4 o) {  // sum over the four k-slots (lanes q = 0..3 of a rollout)
+#ifdef PHNN_BPERMUTE_REDUCE
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     float v = o[c];
@@ -632,6 +638,19 @@ DEV f32x4 to4_kslots(f32x4 o) {  // sum over the four k-slots (lanes q = 0..3 of
     o[c] = v;
   }
   return o;
+#else
+  f32x4 b;
+  asm volatile("v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+               "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+               "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 0"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]));
+  o = o + b;
+  asm volatile("v_mov_b32 %4, %0\n\tv_mov_b32 %5, %1\n\tv_mov_b32 %6, %2\n\tv_mov_b32 %7, %3\n\t"
+               "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+               "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\ts_nop 0"
+               : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]));
+  return o + b;
+#endif
 }
 
 template <int TI>
@@ -718,9 +737,17 @@ DEV void gather16(float* scr, Lane ln, f32x4 mine, float (&out)[16]) {
 }
 
 DEV float reduce_q(float v) {  // sum over the 4 lanes (q = 0..3) of a rollout
+#ifdef PHNN_BPERMUTE_REDUCE
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
+#else
+  float b;
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(v), "=&v"(b));
+  v += b;
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(v), "=&v"(b));
+  return v + b;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
