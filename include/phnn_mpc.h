@@ -144,6 +144,13 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
 /* Replace the weights of an existing handle (same description): re-packs and re-uploads the LDS image on `stream`
  * order.  What load_state_dict / an optimizer step on the reference module amounts to for the engine. */
 int phnn_update_weights(phnn_handle* h, const float* weights_host, size_t n_floats, void* stream);
+/* The same from a blob that already lives on the handle's device (e.g. the parameters of a module trained there, laid
+ * out as for phnn_create): zero-padding to the kernel width and packing run as ONE small kernel in stream order -- no
+ * device-to-host copy, host packing or upload, nothing to wait for on the host, and the call may be captured into a HIP
+ * graph.  Same image as phnn_update_weights bit for bit, except the constants of CANONICAL models that go through
+ * exp / log1p (softplus(R_diag_raw), the mass-matrix constants), where host and device math libraries may differ in the
+ * last bit.  Kernels launched later on `stream` see the new weights; work on other streams must be ordered by the caller. */
+int phnn_update_weights_dev(phnn_handle* h, const float* weights_dev, size_t n_floats, void* stream);
 int phnn_destroy(phnn_handle* h);
 /* Message of the last failing call on this handle (or of the last failing phnn_create if h == NULL). */
 const char* phnn_last_error(const phnn_handle* h);
@@ -292,6 +299,11 @@ int phnn_plant_step(phnn_handle* h, const phnn_plant* plant, double* state_dev, 
  * dst[b,H-1] = 0 (u (B,H,m), shift by one step).  Also advances *step_dev by one when step_dev != NULL. */
 int phnn_shift_controls(phnn_handle* h, const float* src_dev, float* dst_dev, int64_t B, int32_t H, int32_t m,
                         int32_t* step_dev, void* stream);
+
+/* Introspection for tests: copies the packed weight image the kernels stage into LDS (phnn_kernels.hip.h layouts; a
+ * device-resident private format) to image_host after the work queued on `stream`, and waits for the copy.
+ * *image_floats (may be NULL) receives its size; image_host == NULL only queries the size. */
+int phnn_read_image(phnn_handle* h, float* image_host, size_t n_floats, size_t* image_floats, void* stream);
 
 /* Introspection for benches/tests: name of the kernel variant selected for this handle, rollouts per
  * workgroup, LDS bytes staged per workgroup. */

@@ -27,7 +27,7 @@ LIB_PATH = os.environ.get("PHNN_LIB_PATH") or os.path.join(_HERE, "csrc", "libph
 
 # every symbol include/phnn_mpc.h declares
 EXPORTED = [
-    "phnn_create", "phnn_create_ex", "phnn_update_weights", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
+    "phnn_create", "phnn_create_ex", "phnn_update_weights", "phnn_update_weights_dev", "phnn_read_image", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
     "phnn_model_vjp", "phnn_rollout_fwd", "phnn_workspace_bytes", "phnn_rollout_grad", "phnn_rollout_vjp",
     "phnn_rollout_trajectory", "phnn_rollout_trajectory_ws", "phnn_wgrad_workspace_bytes", "phnn_wgrad_record_info", "phnn_rollout_wgrad", "phnn_model_wgrad",
     "phnn_adam_step", "phnn_plant_step", "phnn_shift_controls", "phnn_kernel_info", "phnn_variant_name",
@@ -148,6 +148,10 @@ def load_library():
     lib.phnn_create_ex.restype = C.c_int
     lib.phnn_update_weights.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, vp]
     lib.phnn_update_weights.restype = C.c_int
+    lib.phnn_update_weights_dev.argtypes = [vp, f32p, C.c_size_t, vp]
+    lib.phnn_update_weights_dev.restype = C.c_int
+    lib.phnn_read_image.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_size_t), vp]
+    lib.phnn_read_image.restype = C.c_int
     lib.phnn_destroy.argtypes = [vp]
     lib.phnn_destroy.restype = C.c_int
     lib.phnn_last_error.argtypes = [vp]

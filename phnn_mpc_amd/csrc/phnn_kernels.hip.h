@@ -3261,8 +3261,13 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     }
   };
   const long long G = gridDim.x, last = p.n_rec - 1;
+#ifdef PHNN_WG_DEBUG_CACHED
+  auto slice_of = [&](long long r) { return p.rec + ((r < last ? r : last) & 255) * Rec::SIZE; };
+  auto tape_of = [&](long long r) { return TAPES ? p.tapes + ((r < last ? r : last) & 255) * (long long)p.tape_stride : nullptr; };
+#else
   auto slice_of = [&](long long r) { return p.rec + (r < last ? r : last) * Rec::SIZE; };  // clamped: a prefetch past the end re-reads the last record
   auto tape_of = [&](long long r) { return TAPES ? p.tapes + (r < last ? r : last) * (long long)p.tape_stride : nullptr; };
+#endif
   if ((long long)blockIdx.x < p.n_rec) {
     long long r = blockIdx.x;
     RecSlice<NB> cur, nxt;
@@ -3276,9 +3281,17 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
       nxt.load(slice_of(r + G), Rec::VEC / 4, Rec::oSmall, w, ln, tape_of(r + G));
       // (measured and not kept: stage before gemm +4 %; the two waves of a SIMD in opposite orders: spills, +50 %;
       // sched_group_barrier MFMA / VALU interleaving: no change)
+#ifndef PHNN_WG_DEBUG_NOGEMM
       gemm(buf);
+#endif
+#ifndef PHNN_WG_DEBUG_NOSTAGE
       stage(cur, buf ^ 1);
+#else
+      aB3 += cur.big[0][0] + cur.big[1][0] + cur.big[2][0] + cur.big[3][0] + cur.x[0] + cur.v[0] + cur.lam[0] + cur.dH[0] + cur.rv[0] + cur.uu[0] + cur.Hbar;
+#endif
+#ifndef PHNN_WG_DEBUG_NOBARRIER
       __syncthreads();
+#endif
     }
     gemm(buf);
   }

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "phnn_variants.h"
+#include "phnn_pack.h"
 
 namespace {
 
@@ -240,227 +240,8 @@ int pick_variant(const phnn_desc* d, const phnn_options& opt, std::string* why) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS image packing
+// LDS image packing: phnn_pack.h (shared with the device-side packer of phnn_update_weights_dev)
 // ---------------------------------------------------------------------------------------------
-template <int HID>
-void pack_in_frag(float* dst, const float* W, int nin) {  // W (HID, nin) -> [T][64]
-  for (int nt = 0; nt < HID / 16; ++nt)
-    for (int lane = 0; lane < 64; ++lane) {
-      int i = lane & 15, q = lane >> 4;
-      dst[nt * 64 + lane] = q < nin ? W[(size_t)(16 * nt + i) * nin + q] : 0.f;
-    }
-}
-// f16x2 input layer (in_layer_h): [T][64] lanes x 8 halves; lane (i,0): hi(W[u][0..3]) twice, lane (i,1): lo(W[u][0..3])
-// twice, lanes q >= 2: zeros
-template <int HID>
-void pack_in_frag_h(float* dstf, const float* W, int nin) {
-  _Float16* dst = reinterpret_cast<_Float16*>(dstf);
-  for (int nt = 0; nt < HID / 16; ++nt)
-    for (int lane = 0; lane < 64; ++lane) {
-      int i = lane & 15, q = lane >> 4;
-      for (int j = 0; j < 8; ++j) {
-        int c = j & 3;
-        float x = (q < 2 && c < nin) ? W[(size_t)(16 * nt + i) * nin + c] : 0.f;
-        _Float16 h = (_Float16)x;
-        _Float16 l = (_Float16)(x - (float)h);
-        dst[(size_t)(nt * 64 + lane) * 8 + j] = q == 0 ? h : (q == 1 ? l : (_Float16)0.f);
-      }
-    }
-}
-template <int HID>
-void pack_in_frag_T(float* dst, const float* W, int nout) {  // W (nout, HID): frag of W^T (HID, nout)
-  for (int nt = 0; nt < HID / 16; ++nt)
-    for (int lane = 0; lane < 64; ++lane) {
-      int i = lane & 15, q = lane >> 4;
-      dst[nt * 64 + lane] = q < nout ? W[(size_t)q * HID + 16 * nt + i] : 0.f;
-    }
-}
-void pack_rows(float* dst, const float* W, int rows, int cols, int ld) {  // row-major (rows, cols) -> ld-padded
-  for (int r = 0; r < rows; ++r)
-    for (int c = 0; c < cols; ++c) dst[(size_t)r * ld + c] = W[(size_t)r * cols + c];
-}
-void pack_cols_as_rows(float* dst, const float* W, int rows, int cols, int ld) {  // dst[c][r] = W[r][c]
-  for (int r = 0; r < rows; ++r)
-    for (int c = 0; c < cols; ++c) dst[(size_t)c * ld + r] = W[(size_t)r * cols + c];
-}
-
-uint16_t bf16_rne(float x) {
-  uint32_t u;
-  memcpy(&u, &x, 4);
-  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-float bf16_to_f32(uint16_t b) {
-  uint32_t u = ((uint32_t)b) << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-
-// W (HID x HID, row-major) -> three bf16 parts [HID][RS] with the columns in k-slot order: position
-// 32s + 8q + j holds unit 32s + (j < 4 ? 4q + j : 16 + 4q + j - 4)  (phnn_kernels.hip.h, "bf16x3 products")
-template <int HID>
-void pack_bf16x3(float* dstf, const float* W) {
-  using I = BfImg<HID>;
-  uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
-  for (int r = 0; r < HID; ++r)
-    for (int pos = 0; pos < HID; ++pos) {
-      int s = pos / 32, w = pos % 32, q = w / 8, j = w % 8;
-      int u = 32 * s + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
-      float x = W[(size_t)r * HID + u];
-      uint16_t h = bf16_rne(x);
-      float r1 = x - bf16_to_f32(h);
-      uint16_t m = bf16_rne(r1);
-      uint16_t l = bf16_rne(r1 - bf16_to_f32(m));
-      size_t at = (size_t)r * I::RS + pos;
-      dst[at] = h;
-      dst[(size_t)I::PART / 2 + at] = m;
-      dst[(size_t)I::PART + at] = l;
-    }
-}
-
-// W -> two f16 parts of S * W in the same permuted layout; returns the power of two S.  S = 1 while max|W| lies in
-// [0.5, 1024): the hi/lo pair then resolves 2^-25 absolute, i.e. <= 2^-24 of the largest weight, and f16's range is
-// far away.  Smaller matrices are scaled up into [0.5, 1) (keeps that relative resolution), larger ones down.
-template <int HID>
-float pack_f16x2(float* dstf, const float* W) {
-  using I = HfImg<HID>;
-  float mx = 0.f;
-  for (int k = 0; k < HID * HID; ++k) mx = std::fmax(mx, std::fabs(W[k]));
-  int e = 0;
-  if (mx > 0.f && (mx < 0.5f || mx >= 1024.0f)) (void)std::frexp(mx, &e);
-  const float S = std::ldexp(1.0f, -e);
-  _Float16* dst = reinterpret_cast<_Float16*>(dstf);
-  for (int r = 0; r < HID; ++r)
-    for (int pos = 0; pos < HID; ++pos) {
-      int s = pos / 32, w = pos % 32, q = w / 8, j = w % 8;
-      int u = 32 * s + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
-      float x = W[(size_t)r * HID + u] * S;
-      _Float16 h = (_Float16)x;
-      _Float16 l = (_Float16)(x - (float)h);
-      size_t at = (size_t)r * I::RS + pos;
-      dst[at] = h;
-      dst[(size_t)I::PART / 2 + at] = l;
-    }
-  return S;
-}
-
-// FOLD: Tanh models only -- SiLU / ReLU images carry the plain weights (S = Sb = k1 = 1)
-template <int HID, int MM, bool FOLD = true>
-const float* pack_h2(float* dst, const float* p, int nin) {  // H_net: consumes W1,b1,W2,b2,W3,b3 from p
-  using Y = LayH2<HID, MM>;
-  const float* W1 = p; p += (size_t)HID * nin;
-  const float* b1 = p; p += HID;
-  const float* W2 = p; p += (size_t)HID * HID;
-  const float* b2 = p; p += HID;
-  const float* W3 = p; p += HID;
-  const float* b3 = p; p += 1;
-  // 128-wide: tanh's 2 log2(e) is folded into the weights and biases in front of each tanh (kPreScaled in the
-  // kernels); every later use of those pre-activations' scale goes through S and k1 below.
-  const float k1 = (FOLD && kPreScaled<HID / 16>) ? 2.8853900817779268f : 1.0f;
-  std::vector<float> W1s((size_t)HID * nin), W2s((size_t)HID * HID);
-  for (size_t k = 0; k < W1s.size(); ++k) W1s[k] = W1[k] * k1;
-  for (size_t k = 0; k < W2s.size(); ++k) W2s[k] = W2[k] * k1;
-  float S = 1.0f;  // scale carried by the second pre-activation: k1 x (f16x2: the image's power of two)
-  if (MM == MM_BF16X3) pack_bf16x3<HID>(dst + Y::oW2, W2s.data());
-  else if (MM == MM_F16X2) S = pack_f16x2<HID>(dst + Y::oW2, W2s.data());
-  else pack_rows(dst + Y::oW2, W2s.data(), HID, HID, Y::LD);
-  S *= k1;
-  pack_in_frag<HID>(dst + Y::oW1f, W1s.data(), nin);
-  if (MM == MM_F16X2) pack_in_frag_h<HID>(dst + Y::oW1h, W1s.data(), nin);
-  for (int k = 0; k < HID; ++k) dst[Y::oB1 + k] = b1[k] * k1;
-  memcpy(dst + Y::oW3, W3, sizeof(float) * HID);
-  pack_cols_as_rows(dst + Y::oW1T, W1, HID, nin, Y::LR);
-  // Sb: power of two (<= 1) that keeps the backward-type MFMA inputs g2 = w3 (1-a2^2) and
-  // gdot2 = w3 (-2 a2 (1-a2^2)) zdot2 inside f16 range for any weights: |g2| <= max|w3| and, with the
-  // Hessian-vector input normalised below 1, |gdot2| <= 0.77 max|w3| ||W2||_inf ||W1||_inf.  1 for ordinary weights.
-  float Sb = 1.0f;
-  if (MM == MM_F16X2) {
-    float w3max = 0.f, n1 = 0.f, n2 = 0.f;
-    for (int k = 0; k < HID; ++k) w3max = std::fmax(w3max, std::fabs(W3[k]));
-    for (int r = 0; r < HID; ++r) {
-      float a = 0.f, b = 0.f;
-      for (int c = 0; c < nin; ++c) a += std::fabs(W1[(size_t)r * nin + c]);
-      for (int c = 0; c < HID; ++c) b += std::fabs(W2[(size_t)r * HID + c]);
-      n1 = std::fmax(n1, a);
-      n2 = std::fmax(n2, b);
-    }
-    float bound = std::fmax(w3max, 0.77f * w3max * n1 * n2);
-    while (bound * Sb > 1024.0f) Sb *= 0.5f;
-  }
-  for (int k = 0; k < HID; ++k) {
-    dst[Y::oB2 + k] = b2[k] * S;
-    dst[Y::oW3B + k] = W3[k] * Sb;
-    dst[Y::oW3S + k] = W3[k] * Sb / S;
-  }
-  for (int k = 0; k < 4 * Y::LR; ++k) dst[Y::oW1T + k] /= (S * Sb);
-  dst[Y::oB3] = b3[0];
-  dst[Y::oB3 + 1] = 2.8853900817779268f / S;
-  dst[Y::oB3 + 2] = 1.0f / k1;
-  dst[Y::oB3 + 3] = Sb;
-  return p;
-}
-
-template <int HID, int MM, bool FOLD = true>
-const float* pack_h1(float* dst, const float* p, int nin, int nout) {  // R_net / G_net
-  using Y = LayH1<HID, MM>;
-  const float* V1 = p; p += (size_t)HID * nin;
-  const float* c1 = p; p += HID;
-  const float* V2 = p; p += (size_t)nout * HID;
-  const float* c2 = p; p += nout;
-  if (Y::HF) {
-    // Sr * V2 as f16 hi/lo, twice: rows = outputs with the hidden units in k-slot order (forward), and rows =
-    // hidden units with the 16 outputs in natural order (transposed product); Sr = 2^k, max|V2| Sr in [0.5, 1)
-    float mx = 0.f;
-    for (int k = 0; k < nout * HID; ++k) mx = std::fmax(mx, std::fabs(V2[k]));
-    int e = 0;
-    if (mx > 0.f) (void)std::frexp(mx, &e);
-    const float Sr = std::ldexp(1.0f, -e);
-    _Float16* fw = reinterpret_cast<_Float16*>(dst + Y::oV2);
-    _Float16* bw = reinterpret_cast<_Float16*>(dst + Y::oV2T);
-    for (int o = 0; o < nout; ++o)
-      for (int pos = 0; pos < HID; ++pos) {
-        int s = pos / 32, w = pos % 32, q = w / 8, j = w % 8;
-        int u = 32 * s + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
-        float x = V2[(size_t)o * HID + u] * Sr;
-        _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
-        fw[(size_t)o * Y::RS + pos] = h;
-        fw[(size_t)Y::FPART / 2 + (size_t)o * Y::RS + pos] = l;
-        bw[(size_t)u * 16 + o] = h;
-        bw[(size_t)Y::BPART / 2 + (size_t)u * 16 + o] = l;
-      }
-    dst[Y::oSc] = 1.0f / Sr;
-  } else {
-    pack_rows(dst + Y::oV2, V2, nout, HID, Y::LD);
-    dst[Y::oSc] = 1.0f;
-  }
-  const float k1 = (FOLD && kPreScaled<HID / 16>) ? 2.8853900817779268f : 1.0f;  // folded tanh constant (see pack_h2)
-  std::vector<float> V1s((size_t)HID * nin);
-  for (size_t k = 0; k < V1s.size(); ++k) V1s[k] = V1[k] * k1;
-  pack_in_frag<HID>(dst + Y::oV1f, V1s.data(), nin);
-  if (Y::HF) pack_in_frag_h<HID>(dst + Y::oV1h, V1s.data(), nin);
-  for (int k = 0; k < HID; ++k) dst[Y::oC1 + k] = c1[k] * k1;
-  memcpy(dst + Y::oC2, c2, sizeof(float) * nout);
-  pack_cols_as_rows(dst + Y::oV1T, V1, HID, nin, Y::LR);
-  return p;
-}
-
-template <class M>
-void pack_phnn(std::vector<float>& img, const phnn_desc* d, const float* p) {
-  constexpr int N = M::N, HID = M::HID;
-  img.assign(M::IMG, 0.f);
-  const float* J = p; p += N * N;
-  const float* G = nullptr;
-  if (d->fixed_G) { G = p; p += N * M::MI; }
-  constexpr bool FOLD = M::ACT == ACT_TANH;
-  p = pack_h1<HID, M::MM, FOLD>(img.data() + M::oR, p, N, N * N);
-  p = pack_h2<HID, M::MM, FOLD>(img.data() + M::oH, p, N);
-  if (!d->fixed_G) p = pack_h1<HID, M::MM, FOLD>(img.data() + M::oGn, p, N, N * M::MI);
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) img[M::oJ + i * N + j] = J[i * N + j] - J[j * N + i];  // src/pHNN.py:83, no 1/2
-  if (G)
-    for (int i = 0; i < N * M::MI; ++i) img[M::oG + i] = G[i];  // row-major (N, MI)
-}
-
 // ---------------------------------------------------------------------------------------------
 // Width padding: kernels exist for hidden widths 64 and 128.  Any narrower MLP is embedded EXACTLY by adding
 // hidden units with zero weights and zero bias (tanh(0) = 0 feeds zero weights; their (1 - a^2) factors multiply
@@ -597,140 +378,34 @@ std::vector<int> unpad_map(const phnn_desc* d, const phnn_desc* pd) {
   return map;
 }
 
-float softplus_host(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-
-template <class M>
-void pack_canon(std::vector<float>& img, const phnn_desc* d, const float* p) {
-  constexpr int HID = M::HID;
-  img.assign(M::IMG, 0.f);
-  const float* Rd = p; p += 4;
-  const float* G = p; p += 4 * M::MI;
-  float* c = img.data() + M::oC;
-  if (M::MT == MASS_CARTPOLE) {
-    float log_a = p[0], b = p[1], log_c = p[2];
-    p += 3;
-    c[0] = expf(log_a) + 1e-3f;  // src/mass_matrix.py:286-288
-    c[1] = b;
-    c[2] = expf(log_c) + 1e-3f;
-  } else if (M::MT == MASS_CONSTANT) {
-    // L = tril(L_tril) with softplus(diag) + 1e-3; M = L L^T; M^-1 = L^-T L^-1  (src/mass_matrix.py:141-152, 183-194)
-    const float l00 = softplus_host(p[0]) + 1e-3f, l10 = p[2], l11 = softplus_host(p[3]) + 1e-3f;
-    p += 4;
-    c[0] = l00 * l00;
-    c[1] = l00 * l10;
-    c[2] = l10 * l10 + l11 * l11;
-    const float i00 = 1.0f / l00, i11 = 1.0f / l11, i10 = -l10 / (l00 * l11);
-    float* cw = img.data() + M::oCW;
-    cw[0] = i00 * i00 + i10 * i10;
-    cw[1] = i10 * i11;
-    cw[2] = i11 * i11;
-  } else {  // M_net.mlp (already padded to 64): 2 -> 64 -> 64 -> out
-    const int nout = M::MT == MASS_DIAGONAL ? 2 : 3;
-    float* dm = img.data() + M::oMn;
-    const float* W1 = p; p += 64 * 2;
-    const float* b1 = p; p += 64;
-    const float* W2 = p; p += 64 * 64;
-    const float* b2 = p; p += 64;
-    const float* Wo = p; p += (size_t)nout * 64;
-    const float* bo = p; p += nout;
-    pack_in_frag<64>(dm + LayM::oW1f, W1, 2);
-    memcpy(dm + LayM::oB1, b1, sizeof(float) * 64);
-    pack_rows(dm + LayM::oW2, W2, 64, 64, LayM::LD);
-    memcpy(dm + LayM::oB2, b2, sizeof(float) * 64);
-    pack_rows(dm + LayM::oWo, Wo, nout, 64, LayM::LR);
-    memcpy(dm + LayM::oBo, bo, sizeof(float) * nout);
-    pack_in_frag_T<64>(dm + LayM::oWoTf, Wo, nout);
-    pack_cols_as_rows(dm + LayM::oW1T, W1, 64, 2, LayM::LR);
-  }
-  p = pack_h2<HID, M::MM, M::ACT == ACT_TANH>(img.data() + M::oH, p, 4);
-  for (int i = 0; i < 4; ++i) c[4 + i] = softplus_host(Rd[i]) + 1e-4f;  // src/pHNN_canonical.py:162
-  // softplus'(raw) = sigmoid(raw) (threshold 20 as torch.nn.functional.softplus): the weight-gradient kernels need it
-  for (int i = 0; i < 4; ++i) c[8 + i] = Rd[i] > 20.f ? 1.0f : (float)(1.0 / (1.0 + std::exp(-(double)Rd[i])));
-  for (int i = 0; i < 4 * M::MI; ++i) c[12 + i] = G[i];  // row-major (4, MI)
-}
-
-template <class M>
-void pack_ode(std::vector<float>& img, const phnn_desc* d, const float* p) {
-  constexpr int N = M::N, HID = M::HID;
-  const int nin = N + 1;
-  img.assign(M::IMG, 0.f);
-  const float* W1 = p; p += (size_t)HID * nin;
-  const float* b1 = p; p += HID;
-  const float* W2 = p; p += (size_t)HID * HID;
-  const float* b2 = p; p += HID;
-  const float* W3 = p; p += (size_t)HID * HID;
-  const float* b3 = p; p += HID;
-  const float* W4 = p; p += (size_t)N * HID;
-  const float* b4 = p; p += N;
-  float S2 = 1.0f, S3 = 1.0f;  // power-of-two scales carried by the f16x2 images
-  pack_in_frag<HID>(img.data() + M::oW1f, W1, nin);
-  memcpy(img.data() + M::oB1, b1, sizeof(float) * HID);
-  if (M::MM == MM_F16X2) {
-    S2 = pack_f16x2<HID>(img.data() + M::oW2, W2);
-    S3 = pack_f16x2<HID>(img.data() + M::oW3, W3);
-  } else {
-    pack_rows(img.data() + M::oW2, W2, HID, HID, M::LD);
-    pack_rows(img.data() + M::oW3, W3, HID, HID, M::LD);
-  }
-  for (int k = 0; k < HID; ++k) {
-    img[M::oB2 + k] = b2[k] * S2;
-    img[M::oB3 + k] = b3[k] * S3;
-  }
-  pack_rows(img.data() + M::oW4r, W4, N, HID, M::LR);
-  memcpy(img.data() + M::oB4, b4, sizeof(float) * N);
-  pack_in_frag_T<HID>(img.data() + M::oW4f, W4, N);
-  for (int r = 0; r < HID; ++r)
-    for (int c = 0; c < nin && c < 4; ++c) img[M::oW1T + (size_t)c * M::LR + r] = W1[(size_t)r * nin + c];
-  for (int k = 0; k < 4 * M::LR; ++k) img[M::oW1T + k] /= (S2 * S3);
-  if (M::WIDE) {  // control column of W1: second k-step fragment (k-slot q = 0) and its replicated-row image
-    for (int nt = 0; nt < HID / 16; ++nt)
-      for (int lane = 0; lane < 16; ++lane) img[M::oW1fu + nt * 64 + lane] = W1[(size_t)(16 * nt + lane) * nin + N];
-    for (int r = 0; r < HID; ++r) img[M::oW1Tu + r] = W1[(size_t)r * nin + N] / (S2 * S3);
-  }
-  img[M::oSC + 0] = 2.8853900817779268f / S2;
-  img[M::oSC + 1] = 2.8853900817779268f / S3;
-}
-
 void pack_image(int v, std::vector<float>& img, const phnn_desc* d, const float* blob) {
   switch (v) {
-    case V_PHNN_4_128_FIX: pack_phnn<M_PHNN_4_128_FIX>(img, d, blob); break;
-    case V_PHNN_4_64_FIX: pack_phnn<M_PHNN_4_64_FIX>(img, d, blob); break;
-    case V_PHNN_2_64_GNET: pack_phnn<M_PHNN_2_64_GNET>(img, d, blob); break;
-    case V_PHNN_2_64_FIX: pack_phnn<M_PHNN_2_64_FIX>(img, d, blob); break;
-    case V_CANON_128: pack_canon<M_CANON_128>(img, d, blob); break;
-    case V_CANON_64: pack_canon<M_CANON_64>(img, d, blob); break;
-    case V_ODE_2_128: pack_ode<M_ODE_2_128>(img, d, blob); break;
-    case V_ODE_2_64: pack_ode<M_ODE_2_64>(img, d, blob); break;
-    case V_ODE_3_128: pack_ode<M_ODE_3_128>(img, d, blob); break;
-    case V_PHNN_4_128_FIX_BF: pack_phnn<M_PHNN_4_128_FIX_BF>(img, d, blob); break;
-    case V_CANON_128_BF: pack_canon<M_CANON_128_BF>(img, d, blob); break;
-    case V_PHNN_4_128_FIX_H: pack_phnn<M_PHNN_4_128_FIX_H>(img, d, blob); break;
-    case V_CANON_128_H: pack_canon<M_CANON_128_H>(img, d, blob); break;
-    case V_ODE_2_128_H: pack_ode<M_ODE_2_128_H>(img, d, blob); break;
-    case V_ODE_3_128_H: pack_ode<M_ODE_3_128_H>(img, d, blob); break;
-    case V_ODE_4_128: pack_ode<M_ODE_4_128>(img, d, blob); break;
-    case V_PHNN_4_128_GNET_H: pack_phnn<M_PHNN_4_128_GNET_H>(img, d, blob); break;
-    case V_PHNN_2_128_GNET_H: pack_phnn<M_PHNN_2_128_GNET_H>(img, d, blob); break;
-    case V_PHNN_2_128_FIX_H: pack_phnn<M_PHNN_2_128_FIX_H>(img, d, blob); break;
-    case V_PHNN_4_64_FIX_H: pack_phnn<M_PHNN_4_64_FIX_H>(img, d, blob); break;
-    case V_PHNN_2_64_GNET_H: pack_phnn<M_PHNN_2_64_GNET_H>(img, d, blob); break;
-    case V_PHNN_2_64_FIX_H: pack_phnn<M_PHNN_2_64_FIX_H>(img, d, blob); break;
-    case V_CANON_64_H: pack_canon<M_CANON_64_H>(img, d, blob); break;
-    case V_ODE_2_64_H: pack_ode<M_ODE_2_64_H>(img, d, blob); break;
-    case V_PHNN_4_128_FIX_H_M2: pack_phnn<M_PHNN_4_128_FIX_H_M2>(img, d, blob); break;
-    case V_PHNN_4_128_GNET_H_M2: pack_phnn<M_PHNN_4_128_GNET_H_M2>(img, d, blob); break;
-    case V_CANON_128_H_M2: pack_canon<M_CANON_128_H_M2>(img, d, blob); break;
-    case V_PHNN_4_128_FIX_SILU: pack_phnn<M_PHNN_4_128_FIX_SILU>(img, d, blob); break;
-    case V_PHNN_4_128_FIX_RELU: pack_phnn<M_PHNN_4_128_FIX_RELU>(img, d, blob); break;
-    case V_CANON_128_SILU: pack_canon<M_CANON_128_SILU>(img, d, blob); break;
-    case V_CANON_128_RELU: pack_canon<M_CANON_128_RELU>(img, d, blob); break;
-    case V_ODE_2_128_RELU: pack_ode<M_ODE_2_128_RELU>(img, d, blob); break;
-    case V_ODE_4_128_RELU: pack_ode<M_ODE_4_128_RELU>(img, d, blob); break;
-    case V_CANON_128_H_MCONST: pack_canon<M_CANON_128_H_MCONST>(img, d, blob); break;
-    case V_CANON_128_H_MDIAG: pack_canon<M_CANON_128_H_MDIAG>(img, d, blob); break;
-    case V_CANON_128_H_MFULL: pack_canon<M_CANON_128_H_MFULL>(img, d, blob); break;
+#define PHNN_CASE(V, M, NAME)                       \
+  case V:                                           \
+    img.assign(M::IMG, 0.f);                        \
+    PackOf<M>::run(img.data(), d, blob, nullptr);   \
+    break;
+    PHNN_FOR_EACH_VARIANT(PHNN_CASE)
+#undef PHNN_CASE
     default: break;
   }
+}
+
+// For every entry of the PADDED blob, its index in the caller's blob (-1: padding).  pad_model only copies, so running
+// it on a blob whose entries are their own index + 1 (exact in float32 below 2^24) reads the map off.
+bool pad_source_map(const phnn_desc* d, std::vector<int>* map) {
+  const size_t n = weight_count(d);
+  if (n == 0 || n >= (1u << 24)) return false;
+  std::vector<float> probe(n), padded;
+  for (size_t k = 0; k < n; ++k) probe[k] = (float)(k + 1);
+  phnn_desc pd;
+  std::string why;
+  if (!pad_model(d, probe.data(), &pd, &padded, &why)) return false;
+  const float* src = padded.empty() ? probe.data() : padded.data();
+  const size_t np = padded.empty() ? n : padded.size();
+  map->resize(np);
+  for (size_t k = 0; k < np; ++k) (*map)[k] = src[k] > 0.f ? (int)src[k] - 1 : -1;
+  return true;
 }
 
 }  // namespace
@@ -747,6 +422,9 @@ struct phnn_handle {
   SplitSet sp;       // split-tile kernels for small batches (has_split)
   bool has_split;
   int* d_unpad;      // index map original blob -> padded blob (k_wgrad_finish)
+  int* d_padsrc;     // index map padded blob -> original blob, -1 = padding (phnn_update_weights_dev)
+  float* d_pblob;    // scratch of the device-side packer: the padded blob
+  int n_pad;         // floats of the padded blob
   int n_params;      // floats of the original blob
   float* d_img;
   float* h_img;      // pinned staging copy of the image (phnn_update_weights uploads from it asynchronously)
@@ -911,6 +589,9 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
   h->h_img = nullptr;
   h->up_done = nullptr;
   h->d_unpad = nullptr;
+  h->d_padsrc = nullptr;
+  h->d_pblob = nullptr;
+  h->n_pad = 0;
   h->n_params = (int)n_floats;
   kernel_set(v, &h->ks);
   h->has_wgrad = phnn_wgrad_kernels(v, &h->wg);
@@ -972,9 +653,20 @@ int phnn_create_ex(const phnn_desc* desc, const float* weights_host, size_t n_fl
     e = hipMalloc(reinterpret_cast<void**>(&h->d_unpad), sizeof(int) * map.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_unpad, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess) {
+    std::vector<int> src;
+    if (pad_source_map(desc, &src)) {
+      h->n_pad = (int)src.size();
+      e = hipMalloc(reinterpret_cast<void**>(&h->d_padsrc), sizeof(int) * src.size());
+      if (e == hipSuccess) e = hipMemcpy(h->d_padsrc, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_pblob), sizeof(float) * src.size());
+    }
+  }
   if (e != hipSuccess) {
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->d_unpad) (void)hipFree(h->d_unpad);
+    if (h->d_padsrc) (void)hipFree(h->d_padsrc);
+    if (h->d_pblob) (void)hipFree(h->d_pblob);
     (void)hipFree(h->d_img);
     delete h;
     return hip_fail(nullptr, e, "upload of the weights image");
@@ -1015,12 +707,37 @@ int phnn_update_weights(phnn_handle* h, const float* weights_host, size_t n_floa
   return PHNN_OK;
 }
 
+int phnn_update_weights_dev(phnn_handle* h, const float* weights_dev, size_t n_floats, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!weights_dev) return fail(h, PHNN_ERR_INVALID_ARG, "weights_dev is NULL");
+  if (n_floats != (size_t)h->n_params) {
+    char buf[128];
+    snprintf(buf, sizeof buf, "weight blob has %zu floats, the handle's model needs %d", n_floats, h->n_params);
+    return fail(h, PHNN_ERR_INVALID_ARG, buf);
+  }
+  if (!h->d_padsrc || !h->d_pblob) return fail(h, PHNN_ERR_UNSUPPORTED, "no device-side packer for this handle");
+  PHNN_ON_DEVICE(h);
+  PackParams p;
+  p.orig = weights_dev;
+  p.pad_src = h->d_padsrc;
+  p.n_pad = h->n_pad;
+  p.pblob = h->d_pblob;
+  p.img = h->d_img;
+  p.pdesc = h->pdesc;
+  const int rc = phnn_pack_launch(h->variant, p, (hipStream_t)stream);
+  if (rc < 0) return fail(h, PHNN_ERR_UNSUPPORTED, "no device-side packer for this kernel variant");
+  if (rc != (int)hipSuccess) return hip_fail(h, (hipError_t)rc, "kernel launch (weight packing)");
+  return PHNN_OK;
+}
+
 int phnn_destroy(phnn_handle* h) {
   if (!h) return PHNN_OK;
   if (h->d_img) (void)hipFree(h->d_img);
   if (h->h_img) (void)hipHostFree(h->h_img);
   if (h->up_done) (void)hipEventDestroy(h->up_done);
   if (h->d_unpad) (void)hipFree(h->d_unpad);
+  if (h->d_padsrc) (void)hipFree(h->d_padsrc);
+  if (h->d_pblob) (void)hipFree(h->d_pblob);
   delete h;
   return PHNN_OK;
 }
@@ -1363,6 +1080,19 @@ int phnn_shift_controls(phnn_handle* h, const float* src_dev, float* dst_dev, in
                      (hipStream_t)stream, src_dev, dst_dev, (long long)B, (int)H, (int)m, step_dev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(h, e, "shift launch");
+  return PHNN_OK;
+}
+
+int phnn_read_image(phnn_handle* h, float* image_host, size_t n_floats, size_t* image_floats, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (image_floats) *image_floats = h->img_floats;
+  if (!image_host) return PHNN_OK;
+  if (n_floats < h->img_floats) return fail(h, PHNN_ERR_INVALID_ARG, "image_host is smaller than the image");
+  PHNN_ON_DEVICE(h);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(image_host, h->d_img, sizeof(float) * h->img_floats, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hip_fail(h, e, "hipMemcpyAsync(read image)");
   return PHNN_OK;
 }
 

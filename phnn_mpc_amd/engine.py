@@ -88,6 +88,27 @@ class RolloutEngine:
         rc = self.lib.phnn_update_weights(self.h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, self._stream())
         _check(self.lib, self.h, rc)
 
+    def update_weights_dev(self, blob_dev):
+        """The same from a float32 blob on the engine's device (weights.pack_state_dict order, e.g. torch.cat of the
+        module's parameters and buffers): padded and packed by one small kernel in stream order -- no device-to-host copy,
+        host packing or upload (phnn_update_weights_dev)."""
+        if blob_dev.device != self.device or blob_dev.dtype != torch.float32 or not blob_dev.is_contiguous():
+            raise PhnnError("update_weights_dev: a contiguous float32 tensor on the engine's device is required")
+        if blob_dev.numel() != self.blob.size:
+            raise PhnnError("update_weights_dev: the blob describes another architecture")
+        self._tape_token = None  # tapes of the old weights
+        rc = self.lib.phnn_update_weights_dev(self.h, blob_dev.data_ptr(), blob_dev.numel(), self._stream())
+        _check(self.lib, self.h, rc)
+
+    def read_image(self):
+        """The packed weight image as the kernels stage it (tests: host-packed vs device-packed)."""
+        n = C.c_size_t()
+        _check(self.lib, self.h, self.lib.phnn_read_image(self.h, None, 0, C.byref(n), None))
+        out = np.empty(n.value, np.float32)
+        rc = self.lib.phnn_read_image(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, None, self._stream())
+        _check(self.lib, self.h, rc)
+        return out
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.phnn_destroy(self.h)

@@ -179,9 +179,22 @@ class _EngineBacked(nn.Module):
         elif self._packed_fp is not None:
             fp = self._fingerprint()
             if fp != self._packed_fp:
-                self._engine.update_weights(self.state_dict())
+                self._repack()
                 self._packed_fp = fp
         return self._engine
+
+    def _repack(self):
+        """New parameter values -> the engine's weight image.  Parameters that live on the engine's device are
+        concatenated there (blob order of weights.blob_layout) and packed by the device-side packer
+        (phnn_update_weights_dev): an optimizer step then costs no device-to-host copy, host packing or upload.
+        Anything else goes through the host packer."""
+        sd = self.state_dict()
+        eng = self._engine
+        if hasattr(eng, "update_weights_dev") and all(t.device == eng.device for t in sd.values()):
+            blob = torch.cat([sd[k].detach().reshape(-1).to(torch.float32) for k, _, _ in eng.layout])
+            eng.update_weights_dev(blob)
+        else:
+            eng.update_weights(sd)
 
     def _activation_name(self):
         for mod in self.modules():

@@ -19,6 +19,6 @@ for t in mpc grad wgrad split; do
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$ROOT/build/ab/lib_$name.so" $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$ROOT/build/ab/lib_$name.so" $objs "$src/phnn_pack.o"
 rm -f "$ROOT/build/ab/"*_"$name.o"
 echo "build/ab/lib_$name.so"
