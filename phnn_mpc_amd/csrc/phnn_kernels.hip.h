@@ -326,6 +326,31 @@ DEV void sq_fwd_bf(Act<T>& o, const float* Wimg, Lane ln, const Split3<T>& in) {
   keep_lds_reads_local();
   matrix_phase_begin();
   const char* base = reinterpret_cast<const char*>(Wimg) + ln.i * (I::RS * 2) + ln.q * 16;
+#ifdef PHNN_PREFETCH_BF
+  {  // fragments of group g + 1 requested before the MFMAs of group g (as sq_fwd_h)
+    bf16x8 a[2][2][3];
+    auto loadg = [&](int g, bf16x8 (&dst)[2][3]) {
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          dst[gg][p] = *reinterpret_cast<const bf16x8*>(base + p * I::PART + (n0 + gg) * 16 * (I::RS * 2) + s * 64);
+    };
+    constexpr int NG = (T / 2) * (T / 2);
+    loadg(0, a[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) loadg(g + 1, a[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+      mfma6x2(o.v[n0], o.v[n0 + 1], a[g & 1], in.h[s], in.m[s], in.l[s]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    matrix_phase_end();
+    return;
+  }
+#endif
 #pragma unroll
   for (int n0 = 0; n0 < T; n0 += 2) {
 #pragma unroll
@@ -355,6 +380,37 @@ DEV void sq_bwd_bf(Act<T>& o, const float* Wimg, Lane ln, const Split3<T>& in) {
   typedef char __attribute__((address_space(3))) * lds_cp;
   const int a4 = (ln.lane & 15) >> 2, pp = ln.lane & 3;
   lds_cp base = (lds_cp) const_cast<char*>(reinterpret_cast<const char*>(Wimg)) + (4 * ln.q + a4) * (I::RS * 2) + 16 * pp;
+#ifdef PHNN_PREFETCH_BF
+  {
+    bf16x8 a[2][2][3];
+    auto loadg = [&](int g, bf16x8 (&dst)[2][3]) {
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int nt = n0 + gg;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          lds_cp off = base + p * I::PART + 32 * s * (I::RS * 2) + (64 * (nt >> 1) + 8 * (nt & 1));
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4)off);
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf4)(off + 16 * (I::RS * 2)));
+          dst[gg][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+    };
+    constexpr int NG = (T / 2) * (T / 2);
+    loadg(0, a[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) loadg(g + 1, a[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int n0 = 2 * (g / (T / 2)), s = g % (T / 2);
+      mfma6x2(o.v[n0], o.v[n0 + 1], a[g & 1], in.h[s], in.m[s], in.l[s]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    matrix_phase_end();
+    return;
+  }
+#endif
 #pragma unroll
   for (int n0 = 0; n0 < T; n0 += 2) {
 #pragma unroll

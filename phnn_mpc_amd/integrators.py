@@ -8,7 +8,7 @@ differentiable w.r.t. y0 and controls through the adjoint kernel (phnn_rollout_v
 import torch
 
 from . import _capi
-from .models import _EngineBacked, ODEFunc, _no_wgrad_warning, grad_params, split_param_grads
+from .models import _EngineBacked, ODEFunc, _no_wgrad_warning, grad_params, live_engine, packed_engine, split_param_grads
 
 
 def _call(model, y, u):
@@ -54,7 +54,7 @@ class _RolloutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y0, controls, model, dt, integrator, keys, *params):
-        eng = model.engine
+        eng = ctx.eng = packed_engine(model)  # _rollout has just checked it against the parameters
         y0d = y0.detach().to(eng.device, torch.float32).contiguous()
         ud = controls.detach().to(eng.device, torch.float32).contiguous()
         # parameters that need gradients: K1 keeps its tapes for the weight-gradient pass of backward()
@@ -69,7 +69,7 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtraj, gdx):
         y0d, ud, traj = ctx.saved_tensors
-        eng = ctx.model.engine
+        eng = live_engine(ctx.eng)
         want_params = bool(ctx.keys) and any(ctx.needs_input_grad[6:])
         nk = len(ctx.keys)
         tb = None if gtraj is None else gtraj.to(eng.device, torch.float32).contiguous()
@@ -91,8 +91,9 @@ class _RolloutFn(torch.autograd.Function):
 
 def _rollout(model, y0, controls, dt, integrator):
     keys, params = [], []
+    eng = model.engine  # re-packs the weights if a parameter has changed
     if torch.is_grad_enabled():
-        if model.engine.has_wgrad:
+        if eng.has_wgrad:
             keys, params = grad_params(model)
         elif any(p.requires_grad for p in model.parameters()):
             _no_wgrad_warning(model)

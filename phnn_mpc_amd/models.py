@@ -59,11 +59,26 @@ def _mlp_from(params, input_dim, output_dim):
                dropout=params["dropout"], layer_norm=params["layer_norm"], bias=params["bias"])
 
 
+def packed_engine(owner):
+    """The engine as the LAST `owner.engine` access left it -- no parameter-change check (one `owner.engine` per public
+    operation does that; walking the module tree for the fingerprint costs tens of microseconds each time)."""
+    eng = getattr(owner, "_engine", None)
+    return eng if eng is not None else owner.engine
+
+
+def live_engine(eng):
+    """The engine a forward pass ran on, for its backward pass."""
+    if getattr(eng, "h", True) is None:
+        raise RuntimeError("the model's engine was rebuilt (refresh_engine / load_state_dict / use_device) between "
+                           "forward and backward")
+    return eng
+
+
 def grad_params(owner):
     """Parameters of an engine-backed module that (a) live in the weight blob and (b) require grad, in blob order:
     ([state_dict keys], [nn.Parameter]).  Buffers (G_fixed, the canonical J / G) are not parameters."""
     named = dict(owner.named_parameters())
-    keys = [k for k, _, _ in owner.engine.layout if k in named and named[k].requires_grad]
+    keys = [k for k, _, _ in packed_engine(owner).layout if k in named and named[k].requires_grad]
     return keys, [named[k] for k in keys]
 
 
@@ -111,7 +126,7 @@ class _ModelFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, u, owner, keys, *params):
-        eng = owner.engine
+        eng = ctx.eng = packed_engine(owner)  # call_model_fn has just checked it against the parameters
         xd, ud = x.detach().to(eng.device, torch.float32), u.detach().to(eng.device, torch.float32)
         dx, H = eng.forward(xd, ud)
         ctx.owner, ctx.dev, ctx.keys = owner, x.device, keys
@@ -123,7 +138,7 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gdx, gH):
         xd, ud = ctx.saved_tensors
-        eng = ctx.owner.engine
+        eng = live_engine(ctx.eng)
         gdx = torch.zeros_like(xd) if gdx is None else gdx.to(eng.device, torch.float32)
         want_params = bool(ctx.keys) and any(ctx.needs_input_grad[4:])
         if want_params or (gH is not None and eng.has_wgrad):
@@ -143,8 +158,9 @@ class _ModelFn(torch.autograd.Function):
 def call_model_fn(owner, x, u):
     """_ModelFn with the module's trainable parameters as explicit inputs (so backward can hand them gradients)."""
     keys, params = [], []
+    eng = owner.engine  # re-packs the weights if a parameter has changed
     if torch.is_grad_enabled():
-        if owner.engine.has_wgrad:
+        if eng.has_wgrad:
             keys, params = grad_params(owner)
         elif any(p.requires_grad for p in owner.parameters()):
             _no_wgrad_warning(owner)
