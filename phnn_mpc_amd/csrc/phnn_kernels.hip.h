@@ -46,6 +46,7 @@ DEV f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x
 DEV f32x4 splat4(float s) { return f32x4{s, s, s, s}; }
 
 // 1 - a^2 (derivative of tanh at its output) as one fused op per element instead of mul + sub
+DEV f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 DEV f32x4 dtanh(f32x4 a) { return __builtin_elementwise_fma(-a, a, f32x4{1.0f, 1.0f, 1.0f, 1.0f}); }
 
 DEV float sel4(f32x4 v, int q) { return q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : v[3])); }
@@ -3058,7 +3059,7 @@ struct H1Acc {
     }
     c1 += hb;
 #pragma unroll
-    for (int k = 0; k < N; ++k) V1[k] += hb * x[k];
+    for (int k = 0; k < N; ++k) V1[k] = fma4(hb, splat4(x[k]), V1[k]);
     c2 += ov;
     return h;
   }
@@ -3189,15 +3190,15 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     const f32x4 ad1 = d1 * mfma(w1f, sel4(v, ln.q), splat4(0.f)) * k1inv;
     const f32x4 ad2 = ad2r * c_ad2;
     const f32x4 g2 = w3v * d2;
-    const f32x4 gd2 = (-2.0f * w3v) * (a2 * ad2) + Hbar * g2;
+    const f32x4 gd2 = fma4(-2.0f * w3v, a2 * ad2, Hbar * g2);
     const f32x4 q1 = q1r * c_q1;
     const f32x4 g1 = q1 * d1;
-    const f32x4 gd1 = (qdr * c_qd) * d1 - 2.0f * q1 * (a1 * ad1) + Hbar * g1;
-    aW3 += ad2 + Hbar * a2;
+    const f32x4 gd1 = fma4(qdr * c_qd, d1, fma4(-2.0f * q1, a1 * ad1, Hbar * g1));
+    aW3 += fma4(splat4(Hbar), a2, ad2);
     aB2 += gd2;
     aB1 += gd1;
 #pragma unroll
-    for (int k = 0; k < N; ++k) aW1[k] += gd1 * x[k] + g1 * v[k];
+    for (int k = 0; k < N; ++k) aW1[k] = fma4(gd1, splat4(x[k]), fma4(g1, splat4(v[k]), aW1[k]));
     unsigned* XG = reinterpret_cast<unsigned*>(X + buf * GE::XCH);
     unsigned* XA = XG + GE::oXA;
     float* XH = X + buf * GE::XCH + GE::oXH;
@@ -3208,7 +3209,7 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     if (PHNN) {  // lane (i,q) keeps row q of Jbar
       const float lq = sel4(lam, ln.q), hq = sel4(dH, ln.q);
 #pragma unroll
-      for (int j = 0; j < N; ++j) aJ[j] += lq * dH[j] - lam[j] * hq;
+      for (int j = 0; j < N; ++j) aJ[j] = __builtin_fmaf(lq, dH[j], __builtin_fmaf(-lam[j], hq, aJ[j]));
     } else {
       aRd[0] += cur.rv[2];  // lanes q = 0 hold small vector 4 (the R_diag cotangents); only lane 0's sum is written
       aRd[1] += cur.rv[3];
