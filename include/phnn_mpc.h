@@ -60,11 +60,11 @@ typedef enum { PHNN_MASS_CARTPOLE = 0, PHNN_MASS_CONSTANT = 1, PHNN_MASS_DIAGONA
 
 /* Activation of every MLP in the model (src/NN.py:6-40 takes any nn.Module class -- its default is nn.SiLU;
  * src/pHNN.py:41 resolves it by name; src/baseline_node.py:49-58 offers relu / tanh / elu / gelu).  Tanh is what every
- * shipped config selects and what the fast kernels implement; SiLU and ReLU run on the all-f32 kernels (their
- * activations are unbounded, so the f16 / bf16 split products do not apply; rollouts and VJPs only, no weight-gradient
- * kernels); anything else (OTHER) is refused by phnn_create so that a checkpoint trained with another activation (same
+ * shipped config selects and what the fast kernels implement; SiLU, ReLU, ELU (alpha = 1) and GELU (exact, erf form) run
+ * on the all-f32 kernels (their activations are unbounded, so the f16 / bf16 split products do not apply; rollouts and
+ * VJPs only, no weight-gradient kernels); anything else (OTHER) is refused by phnn_create so that a checkpoint trained with another activation (same
  * keys, same shapes) cannot be run as the wrong network.  One activation per model: all its MLPs must agree. */
-typedef enum { PHNN_ACT_TANH = 0, PHNN_ACT_OTHER = 1, PHNN_ACT_SILU = 2, PHNN_ACT_RELU = 3 } phnn_activation;
+typedef enum { PHNN_ACT_TANH = 0, PHNN_ACT_OTHER = 1, PHNN_ACT_SILU = 2, PHNN_ACT_RELU = 3, PHNN_ACT_ELU = 4, PHNN_ACT_GELU = 5 } phnn_activation;
 
 /* How the hidden x hidden products are evaluated.  DEFAULT: f16x2 for 128-wide models, f32 for
  * narrower ones (f16x2 on the 64-wide trained pendulum model is known to exceed the stated tolerance in long

@@ -14,8 +14,8 @@ MODEL_PHNN, MODEL_CANONICAL, MODEL_ODEFUNC = 0, 1, 2
 INTEG_EULER, INTEG_RK4 = 0, 1
 INTEGRATORS = {"euler": INTEG_EULER, "rk4": INTEG_RK4}
 
-ACT_TANH, ACT_OTHER, ACT_SILU, ACT_RELU = 0, 1, 2, 3
-ACTIVATIONS = {"tanh": ACT_TANH, "silu": ACT_SILU, "relu": ACT_RELU}  # activations with kernels (others: ACT_OTHER, refused)
+ACT_TANH, ACT_OTHER, ACT_SILU, ACT_RELU, ACT_ELU, ACT_GELU = 0, 1, 2, 3, 4, 5
+ACTIVATIONS = {"tanh": ACT_TANH, "silu": ACT_SILU, "relu": ACT_RELU, "elu": ACT_ELU, "gelu": ACT_GELU}  # activations with kernels (others: ACT_OTHER, refused)
 MASS_CARTPOLE, MASS_CONSTANT, MASS_DIAGONAL, MASS_FULL = 0, 1, 2, 3
 WGRAD_ACCUMULATE, WGRAD_TAPES = 1, 2  # flags of phnn_rollout_wgrad / phnn_model_wgrad (include/phnn_mpc.h)
 MATMUL_MODES = {"default": 0, "f32": 1, "bf16x3": 2, "f16x2": 3}

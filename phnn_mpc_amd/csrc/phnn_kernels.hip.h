@@ -884,17 +884,28 @@ DEV void store_rec_scaled(float* dst, Lane ln, const Act<T>& a, float s) {
 
 // ------------------------------------------------------------------------------------------------
 // Activations other than Tanh (src/NN.py:13 defaults to nn.SiLU; src/pHNN.py:41 resolves any nn.* by name;
-// src/baseline_node.py:49-58 offers relu): SiLU and ReLU on the all-f32 kernels.  Their outputs are unbounded, so the
+// src/baseline_node.py:49-58 offers relu, elu, gelu): SiLU, ReLU, ELU and GELU on the all-f32 kernels.  Their outputs are unbounded, so the
 // f16 / bf16 split products (which rely on |tanh| <= 1) do not apply, and phi' / phi'' need the PRE-activation: the
 // tapes of these variants keep z where the Tanh kernels keep a = tanh(z).  Values = phnn_activation.
 // ------------------------------------------------------------------------------------------------
-constexpr int ACT_TANH = 0, ACT_SILU = 2, ACT_RELU = 3;
+constexpr int ACT_TANH = 0, ACT_SILU = 2, ACT_RELU = 3, ACT_ELU = 4, ACT_GELU = 5;
+
+// standard normal density and distribution (nn.GELU, approximate='none': z Phi(z))
+DEV float gelu_pdf(float z) { return 0.3989422804014327f * __builtin_amdgcn_exp2f(z * z * -0.7213475204444817f); }
+DEV float gelu_cdf(float z) { return __builtin_fmaf(0.5f, erff(z * 0.7071067811865476f), 0.5f); }
 
 template <int ACT>
 DEV void act_eval(float z, float& a, float& d1) {  // phi(z), phi'(z)
   if (ACT == ACT_RELU) {
     a = fmaxf(z, 0.f);
     d1 = z > 0.f ? 1.0f : 0.0f;  // torch: subgradient 0 at 0
+  } else if (ACT == ACT_ELU) {  // nn.ELU, alpha = 1: z | expm1(z);  1 | exp(z)
+    a = z > 0.f ? z : expm1f(z);
+    d1 = z > 0.f ? 1.0f : __builtin_amdgcn_exp2f(z * 1.4426950408889634f);
+  } else if (ACT == ACT_GELU) {  // z Phi(z);  Phi(z) + z pdf(z)
+    const float c = gelu_cdf(z);
+    a = z * c;
+    d1 = __builtin_fmaf(z, gelu_pdf(z), c);
   } else {  // SiLU: z s, s (1 + z (1 - s)) with s = sigmoid(z)
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
     a = z * s;
@@ -904,6 +915,8 @@ DEV void act_eval(float z, float& a, float& d1) {  // phi(z), phi'(z)
 template <int ACT>
 DEV float act_d2(float z) {  // phi''(z)
   if (ACT == ACT_RELU) return 0.0f;
+  if (ACT == ACT_ELU) return z > 0.f ? 0.0f : __builtin_amdgcn_exp2f(z * 1.4426950408889634f);
+  if (ACT == ACT_GELU) return gelu_pdf(z) * __builtin_fmaf(-z, z, 2.0f);
   const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
   return s * (1.0f - s) * __builtin_fmaf(z, 1.0f - 2.0f * s, 2.0f);
 }

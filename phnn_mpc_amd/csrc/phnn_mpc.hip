@@ -140,19 +140,27 @@ int matmul_mode(const phnn_options& o, int hid) {
 int pick_variant(const phnn_desc* d, const phnn_options& opt, std::string* why) {
   char buf[256];
   if (d->activation != PHNN_ACT_TANH) {
-    // SiLU / ReLU: whole-tile all-f32 kernels of the cart-pole sized models (narrower nets are zero-padded: phi(0) = 0)
-    const bool silu = d->activation == PHNN_ACT_SILU, relu = d->activation == PHNN_ACT_RELU;
-    if ((silu || relu) && d->m == 1 && opt.matmul_mode != PHNN_MATMUL_BF16X3 && opt.matmul_mode != PHNN_MATMUL_F16X2) {
+    // SiLU / ReLU / ELU / GELU: whole-tile all-f32 kernels of the cart-pole sized models (narrower nets are zero-padded:
+    // phi(0) = 0 for all four)
+    const int a = d->activation;
+    const int ai = a == PHNN_ACT_SILU ? 0 : a == PHNN_ACT_RELU ? 1 : a == PHNN_ACT_ELU ? 2 : a == PHNN_ACT_GELU ? 3 : -1;
+    if (ai >= 0 && d->m == 1 && opt.matmul_mode != PHNN_MATMUL_BF16X3 && opt.matmul_mode != PHNN_MATMUL_F16X2) {
+      static const int phnn_v[4] = {V_PHNN_4_128_FIX_SILU, V_PHNN_4_128_FIX_RELU, V_PHNN_4_128_FIX_ELU, V_PHNN_4_128_FIX_GELU};
+      static const int canon_v[4] = {V_CANON_128_SILU, V_CANON_128_RELU, V_CANON_128_ELU, V_CANON_128_GELU};
+      static const int ode2_v[4] = {V_NONE, V_ODE_2_128_RELU, V_ODE_2_128_ELU, V_ODE_2_128_GELU};  // src/baseline_node.py:49-58 has no silu
+      static const int ode4_v[4] = {V_NONE, V_ODE_4_128_RELU, V_ODE_4_128_ELU, V_ODE_4_128_GELU};
       if (d->kind == PHNN_MODEL_PHNN && d->n == 4 && d->fixed_G && same_hidden(d->h_net, 2, 128) && same_hidden(d->r_net, 1, 128))
-        return silu ? V_PHNN_4_128_FIX_SILU : V_PHNN_4_128_FIX_RELU;
+        return phnn_v[ai];
       if (d->kind == PHNN_MODEL_CANONICAL && d->mass_type == PHNN_MASS_CARTPOLE && d->n == 4 && same_hidden(d->h_net, 2, 128))
-        return silu ? V_CANON_128_SILU : V_CANON_128_RELU;
-      if (d->kind == PHNN_MODEL_ODEFUNC && relu && same_hidden(d->h_net, 3, 128) && (d->n == 2 || d->n == 4))
-        return d->n == 2 ? V_ODE_2_128_RELU : V_ODE_4_128_RELU;
+        return canon_v[ai];
+      if (d->kind == PHNN_MODEL_ODEFUNC && same_hidden(d->h_net, 3, 128) && (d->n == 2 || d->n == 4) &&
+          (d->n == 2 ? ode2_v : ode4_v)[ai] != V_NONE)
+        return (d->n == 2 ? ode2_v : ode4_v)[ai];
     }
-    *why = "activation: Tanh has every kernel family; SiLU / ReLU have all-f32 rollout kernels for the pHNN (n = 4, fixed G) and "
-           "the canonical cart-pole pHNN (hidden widths up to 128), ReLU also for ODEFunc (n = 2 | 4, three hidden layers up to "
-           "128), m = 1, matmul mode default / f32; other activations (src/NN.py takes any nn.Module) have none";
+    *why = "activation: Tanh has every kernel family; SiLU / ReLU / ELU / GELU have all-f32 rollout kernels for the pHNN (n = 4, "
+           "fixed G) and the canonical cart-pole pHNN (hidden widths up to 128), ReLU / ELU / GELU also for ODEFunc (n = 2 | 4, "
+           "three hidden layers up to 128), m = 1, matmul mode default / f32; other activations (src/NN.py takes any nn.Module) "
+           "have none";
     return V_NONE;
   }
   {
@@ -287,7 +295,7 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
   else if (d->kind == PHNN_MODEL_CANONICAL) W = mx <= 64 ? 64 : 128;
   else W = (d->n == 2 && mx <= 64) ? 64 : 128;
   if (d->m > 1) W = 128;  // the m = 2 kernels exist at width 128 only
-  if (d->activation != PHNN_ACT_TANH) W = 128;  // so do the SiLU / ReLU ones
+  if (d->activation != PHNN_ACT_TANH) W = 128;  // so do the SiLU / ReLU / ELU / GELU ones
   if (d->kind == PHNN_MODEL_CANONICAL && d->mass_type != PHNN_MASS_CARTPOLE) W = 128;  // so do the MassMatrixNetwork ones
   if (mx > W || mx < 1) {
     char buf[160];

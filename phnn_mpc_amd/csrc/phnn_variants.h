@@ -42,6 +42,14 @@ enum Variant {
   V_CANON_128_RELU,
   V_ODE_2_128_RELU,
   V_ODE_4_128_RELU,
+  V_PHNN_4_128_FIX_ELU,  // nn.ELU / nn.GELU (src/baseline_node.py:53-56; src/pHNN.py:41 by name)
+  V_PHNN_4_128_FIX_GELU,
+  V_CANON_128_ELU,
+  V_CANON_128_GELU,
+  V_ODE_2_128_ELU,
+  V_ODE_2_128_GELU,
+  V_ODE_4_128_ELU,
+  V_ODE_4_128_GELU,
 };
 
 using M_PHNN_4_128_FIX = PhnnModel<4, 128, true>;
@@ -80,6 +88,14 @@ using M_CANON_128_SILU = CanonModel<128, MM_F32, 1, MASS_CARTPOLE, ACT_SILU>;
 using M_CANON_128_RELU = CanonModel<128, MM_F32, 1, MASS_CARTPOLE, ACT_RELU>;
 using M_ODE_2_128_RELU = OdeModel<2, 128, MM_F32, ACT_RELU>;
 using M_ODE_4_128_RELU = OdeModel<4, 128, MM_F32, ACT_RELU>;
+using M_PHNN_4_128_FIX_ELU = PhnnModel<4, 128, true, MM_F32, 1, ACT_ELU>;
+using M_PHNN_4_128_FIX_GELU = PhnnModel<4, 128, true, MM_F32, 1, ACT_GELU>;
+using M_CANON_128_ELU = CanonModel<128, MM_F32, 1, MASS_CARTPOLE, ACT_ELU>;
+using M_CANON_128_GELU = CanonModel<128, MM_F32, 1, MASS_CARTPOLE, ACT_GELU>;
+using M_ODE_2_128_ELU = OdeModel<2, 128, MM_F32, ACT_ELU>;
+using M_ODE_2_128_GELU = OdeModel<2, 128, MM_F32, ACT_GELU>;
+using M_ODE_4_128_ELU = OdeModel<4, 128, MM_F32, ACT_ELU>;
+using M_ODE_4_128_GELU = OdeModel<4, 128, MM_F32, ACT_GELU>;
 
 struct GradSet {
   void (*grad[2])(RollParams);     // Euler, RK4: recompute the tape
@@ -157,4 +173,12 @@ hipError_t phnn_wgrad_finish(const float* slab, int rows, int PP, const int* map
   X(V_CANON_128_SILU, M_CANON_128_SILU, "canonical<hid=128,silu>") \
   X(V_CANON_128_RELU, M_CANON_128_RELU, "canonical<hid=128,relu>") \
   X(V_ODE_2_128_RELU, M_ODE_2_128_RELU, "odefunc<n=2,hid=128,relu>") \
-  X(V_ODE_4_128_RELU, M_ODE_4_128_RELU, "odefunc<n=4,hid=128,relu>")
+  X(V_ODE_4_128_RELU, M_ODE_4_128_RELU, "odefunc<n=4,hid=128,relu>") \
+  X(V_PHNN_4_128_FIX_ELU, M_PHNN_4_128_FIX_ELU, "phnn<n=4,hid=128,fixedG,elu>") \
+  X(V_PHNN_4_128_FIX_GELU, M_PHNN_4_128_FIX_GELU, "phnn<n=4,hid=128,fixedG,gelu>") \
+  X(V_CANON_128_ELU, M_CANON_128_ELU, "canonical<hid=128,elu>") \
+  X(V_CANON_128_GELU, M_CANON_128_GELU, "canonical<hid=128,gelu>") \
+  X(V_ODE_2_128_ELU, M_ODE_2_128_ELU, "odefunc<n=2,hid=128,elu>") \
+  X(V_ODE_2_128_GELU, M_ODE_2_128_GELU, "odefunc<n=2,hid=128,gelu>") \
+  X(V_ODE_4_128_ELU, M_ODE_4_128_ELU, "odefunc<n=4,hid=128,elu>") \
+  X(V_ODE_4_128_GELU, M_ODE_4_128_GELU, "odefunc<n=4,hid=128,gelu>")

@@ -218,7 +218,8 @@ class _EngineBacked(nn.Module):
                 return mod.activation_name
         return "tanh"
 
-    SUPPORTED_ACTIVATIONS = ("Tanh", "SiLU", "ReLU")  # Tanh: every kernel family; SiLU / ReLU: the all-f32 rollout kernels
+    # Tanh: every kernel family; SiLU / ReLU / ELU (alpha = 1) / GELU (erf form): the all-f32 rollout kernels
+    SUPPORTED_ACTIVATIONS = ("Tanh", "SiLU", "ReLU", "ELU", "GELU")
 
     def set_engine(self, engine):
         """Attach an already built engine (tests use this to run the host logic without a GPU)."""
@@ -248,7 +249,7 @@ class _EngineBacked(nn.Module):
                 raise NotImplementedError(f"{name}: the M_net.mlp kernel implements Tanh, got {mod.activation_name}")
             if isinstance(mod, MLP) and (not mod.plain or mod.activation_name not in self.SUPPORTED_ACTIVATIONS):
                 raise NotImplementedError(
-                    f"{name}: the rollout kernels implement Linear + Tanh / SiLU / ReLU MLPs (bias, no LayerNorm/Dropout); "
+                    f"{name}: the rollout kernels implement Linear + Tanh / SiLU / ReLU / ELU / GELU MLPs (bias, no LayerNorm/Dropout); "
                     f"got activation={mod.activation_name}, plain={mod.plain}")
         acts = {mod.activation_name for mod in self.modules() if isinstance(mod, MLP)}
         if len(acts) > 1:
@@ -436,7 +437,7 @@ class ODEFunc(_EngineBacked):
         acts = {"relu": nn.ReLU, "tanh": nn.Tanh, "elu": nn.ELU, "gelu": nn.GELU}
         if activation not in acts:
             raise ValueError(f"Unknown activation: {activation}")
-        self._plain = activation in ("tanh", "relu") and not layer_norm
+        self._plain = not layer_norm
         self._act = activation
         mods, prev = [], state_dim + action_dim
         for h in hidden_sizes:
@@ -454,7 +455,7 @@ class ODEFunc(_EngineBacked):
 
     def _check_supported(self):
         if not self._plain:
-            raise NotImplementedError("the ODEFunc kernels implement tanh (default) and relu, without LayerNorm")
+            raise NotImplementedError("the ODEFunc kernels implement tanh (default), relu, elu and gelu, without LayerNorm")
 
     def _activation_name(self):
         return self._act

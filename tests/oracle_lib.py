@@ -195,7 +195,9 @@ def load_m2_golden():
 
 M2_MODELS = ["phnn_m2_fix", "phnn_m2_gnet", "canonical_m2"]
 # models with other activations than Tanh (tests/golden/make_golden_act.py): name -> activation
-ACT_MODELS = {"phnn_silu": "silu", "phnn_relu": "relu", "canonical_silu": "silu", "odefunc_relu": "relu"}
+ACT_MODELS = {"phnn_silu": "silu", "phnn_relu": "relu", "canonical_silu": "silu", "odefunc_relu": "relu",
+              "phnn_elu": "elu", "phnn_gelu": "gelu", "canonical_elu": "elu", "canonical_gelu": "gelu",
+              "odefunc_elu": "elu", "odefunc_gelu": "gelu"}
 
 
 def load_named_golden(fname):

@@ -1,5 +1,5 @@
-"""HIP kernels for MLPs with SiLU / ReLU activations (src/NN.py:13 defaults to nn.SiLU; src/pHNN.py:41 resolves any nn.* by
-name; src/baseline_node.py:49-58: relu) against the reference's own outputs (tests/golden/make_golden_act.py) and the
+"""HIP kernels for MLPs with SiLU / ReLU / ELU / GELU activations (src/NN.py:13 defaults to nn.SiLU; src/pHNN.py:41 resolves any nn.* by
+name; src/baseline_node.py:49-58: relu, elu, gelu) against the reference's own outputs (tests/golden/make_golden_act.py) and the
 float64 oracle: model(x,u), VJP, Euler / RK4 rollouts with cost and gradients, tape and recompute adjoints, and the
 drop-in module classes built from a YAML that selects the activation.  Tolerances as for the Tanh models (stated in
 tests/test_gpu_parity.py); ReLU gradients allow one unit's mask flipping where float32 rounds a pre-activation across 0."""
@@ -122,8 +122,25 @@ def test_drop_in_modules_select_the_activation_from_the_yaml(torch, tmp_path):
     with pytest.raises(NotImplementedError, match="ONE activation"):
         pHNN(str(p2)).engine
     for k in ("H_mlp", "R_mlp"):
-        cfg["model"][k]["activation"] = "nn.GELU"
-    p3 = tmp_path / "gelu.yaml"
+        cfg["model"][k]["activation"] = "nn.Softplus"
+    p3 = tmp_path / "softplus.yaml"
     p3.write_text(yaml.safe_dump(cfg))
     with pytest.raises(NotImplementedError):
         pHNN(str(p3)).engine
+
+
+def test_odefunc_module_takes_the_reference_activation_names(torch):
+    """models.ODEFunc(activation=...) (src/baseline_node.py:49-58: relu / tanh / elu / gelu) runs the matching kernels and
+    reproduces the reference's own ODEFunc outputs; LayerNorm stays refused."""
+    from phnn_mpc_amd.models import ODEFunc
+    for name, n in (("odefunc_elu", 2), ("odefunc_gelu", 4)):
+        act = ol.ACT_MODELS[name]
+        g, w = ol.load_golden(name), ol.load_weights(name)
+        f = ODEFunc(n, 1, activation=act)
+        f.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+        f.current_action = torch.tensor(g["fwd_u"][:16])
+        dx = f(0.0, torch.tensor(g["fwd_x"][:16]))
+        assert act in f.engine.variant
+        assert rel(dx.detach().cpu().numpy(), g["fwd_dx_f64"][:16]) < 2e-5
+    with pytest.raises(NotImplementedError, match="LayerNorm"):
+        ODEFunc(2, 1, activation="gelu", layer_norm=True).engine

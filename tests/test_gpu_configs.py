@@ -177,7 +177,7 @@ def test_options_struct_and_weight_updates(torch):
     a, b = e4.forward(g["fwd_x"], g["fwd_u"]), e8.forward(g["fwd_x"], g["fwd_u"])
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     with pytest.raises(PhnnError, match="Tanh"):
-        RolloutEngine(w, activation="GELU")  # Tanh / SiLU / ReLU have kernels (tests/test_gpu_activations.py), nothing else
+        RolloutEngine(w, activation="Softplus")  # Tanh / SiLU / ReLU / ELU / GELU have kernels (tests/test_gpu_activations.py), nothing else
     with pytest.raises(ValueError):
         RolloutEngine(w, matmul="fp8")
     m = _load(pHNN, CFG, "phnn_cartpole", torch)

@@ -51,16 +51,18 @@ def test_struct_sizes_match_header():
 
 def test_activation_is_part_of_the_description():
     """A checkpoint trained with another activation has the same keys and shapes: the description carries the
-    activation explicitly; Tanh, SiLU and ReLU have kernels, everything else is refused (before any device is touched),
+    activation explicitly; Tanh, SiLU, ReLU, ELU and GELU have kernels, everything else is refused (before any device is touched),
     and so are SiLU / ReLU in the split-precision product modes (their activations are unbounded)."""
     lib = _capi.load_library()
-    d, blob = weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="nn.GELU")
+    d, blob = weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="nn.Softplus")
     assert d.activation == _capi.ACT_OTHER
     h = C.c_void_p()
     rc = lib.phnn_create_ex(C.byref(d), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, 0, None, C.byref(h))
     assert rc == -2 and b"Tanh" in lib.phnn_last_error(None)
     ds, blobs = weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="nn.SiLU")
     assert ds.activation == _capi.ACT_SILU and weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="relu")[0].activation == _capi.ACT_RELU
+    assert weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="nn.GELU")[0].activation == _capi.ACT_GELU
+    assert weights.pack_state_dict(ol.load_weights("phnn_cartpole"), activation="elu")[0].activation == _capi.ACT_ELU
     o16 = _capi.Options()
     o16.matmul_mode = _capi.MATMUL_MODES["f16x2"]
     rc = lib.phnn_create_ex(C.byref(ds), blobs.ctypes.data_as(C.POINTER(C.c_float)), blobs.size, 0, C.byref(o16), C.byref(h))
