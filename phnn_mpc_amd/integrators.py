@@ -150,3 +150,14 @@ def rollout_trajectory_differentiable(model, y0, controls, dt, integrator="rk4",
         Hall = _energies(model, traj, controls)
     energies = torch.cat([Hall[:, :1], Hall[:, :-1]], dim=1)
     return traj, energies
+
+
+def compare_integrators(model, y0, controls, dt):
+    """Euler against RK4 on the same controls (src/integrators.py:261-308): both trajectories and energy histories, the
+    per-step distance between the two trajectories and each integrator's energy drift |H_T - H_0|."""
+    with torch.no_grad():
+        et, ee = rollout_trajectory(model, y0, controls, dt, integrator="euler")
+        rt, re = rollout_trajectory(model, y0, controls, dt, integrator="rk4")
+        return {"euler_trajectory": et, "rk4_trajectory": rt, "trajectory_difference": torch.norm(et - rt, dim=-1),
+                "euler_energies": ee, "rk4_energies": re, "euler_energy_drift": torch.abs(ee[:, -1] - ee[:, 0]),
+                "rk4_energy_drift": torch.abs(re[:, -1] - re[:, 0])}

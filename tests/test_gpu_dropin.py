@@ -80,6 +80,14 @@ def test_integrator_functions(torch):
     assert np.abs(npy(I.rk4_step(m, x, u, 0.02)) - r["traj"][:, 1]).max() < 2e-6
     y, H = I.rk4_step_with_energy(m, x, u, 0.02)
     assert np.abs(npy(H) - g["fwd_H_f64"][:32]).max() < 2e-5 and np.abs(npy(y) - r["traj"][:, 1]).max() < 2e-6
+    # compare_integrators (src/integrators.py:261-308): both rollouts, their distance and the energy drifts
+    U3 = torch.tensor(g["fwd_u"][:32, None, :]).repeat(1, 3, 1)
+    cmp_ = I.compare_integrators(m, x, U3, 0.02)
+    et, ee = I.rollout_trajectory(m, x, U3, 0.02, "euler")
+    rt, re = I.rollout_trajectory(m, x, U3, 0.02, "rk4")
+    assert torch.equal(cmp_["euler_trajectory"], et) and torch.equal(cmp_["rk4_trajectory"], rt)
+    assert torch.allclose(cmp_["trajectory_difference"], torch.norm(et - rt, dim=-1)) and cmp_["trajectory_difference"].shape == (32, 4)
+    assert torch.allclose(cmp_["euler_energy_drift"], (ee[:, -1] - ee[:, 0]).abs()) and torch.allclose(cmp_["rk4_energy_drift"], (re[:, -1] - re[:, 0]).abs())
     with pytest.raises(ValueError):
         I.rollout_trajectory(m, x, torch.zeros(32, 3, 1), 0.02, "leapfrog")
     with pytest.raises(ValueError):

@@ -350,6 +350,16 @@ def test_coordinate_transforms_match_reference_g12(ctl):
     assert np.allclose(m.get_velocity_reconstruction(y).numpy(), ctl["ct_vrec"], rtol=1e-6, atol=1e-6)
     q, v = CT.split_state(y)
     assert q.shape == (32, 2) and v.shape == (32, 2)
+    # the remaining helpers of src/coordinate_transforms.py:133-237, against the golden transforms
+    p = torch.tensor(ctl["ct_p"])
+    assert torch.equal(CT.combine_state(q, v), y)
+    assert np.allclose(CT.batch_matrix_vector_product(m.M_net(q), v).numpy(), ctl["ct_p"], rtol=1e-6, atol=1e-6)
+    T = CT.compute_kinetic_energy(q, p, m.M_net)
+    assert T.shape == (32,) and np.allclose(T.numpy(), 0.5 * (ctl["ct_p"] * ctl["ct_y_back"][:, 2:]).sum(1), rtol=1e-5, atol=1e-6)
+    ok, worst = CT.verify_coordinate_transform(y, m.M_net)
+    assert ok and worst < 1e-5
+    err = CT.compute_velocity_reconstruction_error(q, v, p, m.M_net)
+    assert err.shape == (32,) and float(err.max()) < 1e-9
     assert m.M_net.get_parameters_dict().keys() == {"a", "b", "c"}
 
 
