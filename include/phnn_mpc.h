@@ -273,6 +273,29 @@ int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* e
                    int32_t step, const float* cost_dev, float* best_cost_dev, float* best_u_dev, int64_t per,
                    float u_min, float u_max, int32_t has_u_bounds, void* stream);
 
+/* The whole shooting solve behind MPCController.compute_control (src/mpc_controller.py:164-209) and
+ * MPCControllerCanonical.optimize_control (src/mpc_controller_canonical.py:163-228) for B independent problems:
+ * `iters` times { cost and gradient of the current iterate (K1, K2); Adam step (K3) }, a fresh optimizer state per call.
+ *   u_dev (B,H,m): in = initial iterate (zeros for a cold start, the shifted previous solution for a warm start),
+ *                  out = the LAST iterate, unclamped (compute_control returns clamp(u[0]) of it);
+ *   track_best: best_u_dev (B,H,m) / best_cost_dev (B) receive the clamped iterate of lowest cost, the cost of iterate k
+ *               being measured before step k is applied, strict '<' (what optimize_control returns);
+ *   costs_dev (iters,B) or NULL: the cost history (info['costs'] of the canonical controller);
+ *   exp_avg_dev, exp_avg_sq_dev, grad_dev (B,H,m), cost_dev (B), traj_dev (B,H+1,n): caller-owned scratch, overwritten;
+ *   workspace_dev: phnn_workspace_bytes() bytes (K1 -> K2 tape) or NULL (the adjoint recomputes).
+ * The call enqueues the 3 x iters launches on `stream` (stream-ordered, no host synchronisation; small batches run on the
+ * split-tile kernels).  A fused one-launch form was measured and dropped: back-to-back launches are already pipelined, a
+ * single-plant solve is the serial chain of its time steps. */
+typedef struct {
+  int32_t iters;
+  float lr, beta1, beta2, eps; /* torch.optim.Adam: lr, betas (0.9, 0.999), eps 1e-8 */
+  int32_t track_best;
+} phnn_solve_options;
+int phnn_solve(phnn_handle* h, const float* x0_dev, float* u_dev, int64_t B, int32_t H, const phnn_cost* cost,
+               int32_t integrator, float dt, const phnn_solve_options* opt, float* exp_avg_dev, float* exp_avg_sq_dev,
+               float* grad_dev, float* cost_dev, float* traj_dev, void* workspace_dev, float* costs_dev,
+               float* best_cost_dev, float* best_u_dev, void* stream);
+
 /* ---- the plant on the other side of the path ------------------------------------------
  * Ground-truth cart-pole of src/cartpole_simulator.py:63-112: float64, explicit Euler, the standard cart-pole
  * equations in the reference's operation order; termination |x| > x_limit or |theta| > theta_limit.  Defaults of

@@ -30,7 +30,7 @@ EXPORTED = [
     "phnn_create", "phnn_create_ex", "phnn_update_weights", "phnn_update_weights_dev", "phnn_read_image", "phnn_destroy", "phnn_last_error", "phnn_weight_count", "phnn_model_forward",
     "phnn_model_vjp", "phnn_rollout_fwd", "phnn_workspace_bytes", "phnn_rollout_grad", "phnn_rollout_vjp",
     "phnn_rollout_trajectory", "phnn_rollout_trajectory_ws", "phnn_wgrad_workspace_bytes", "phnn_wgrad_record_info", "phnn_rollout_wgrad", "phnn_model_wgrad",
-    "phnn_adam_step", "phnn_plant_step", "phnn_shift_controls", "phnn_kernel_info", "phnn_variant_name",
+    "phnn_adam_step", "phnn_solve", "phnn_plant_step", "phnn_shift_controls", "phnn_kernel_info", "phnn_variant_name",
     "phnn_version",
 ]
 
@@ -54,6 +54,12 @@ class Desc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("fixed_G", C.c_int32),
                 ("h_net", MlpShape), ("r_net", MlpShape), ("g_net", MlpShape), ("activation", C.c_int32),
                 ("mass_type", C.c_int32), ("m_net", MlpShape)]
+
+
+class SolveOptions(C.Structure):
+    """phnn_solve_options"""
+    _fields_ = [("iters", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("track_best", C.c_int32)]
 
 
 class Plant(C.Structure):
@@ -188,6 +194,9 @@ def load_library():
     lib.phnn_adam_step.argtypes = [vp, f32p, f32p, f32p, f32p, i64, C.c_float, C.c_float, C.c_float, C.c_float, i32,
                                    f32p, f32p, f32p, i64, C.c_float, C.c_float, i32, vp]
     lib.phnn_adam_step.restype = C.c_int
+    lib.phnn_solve.argtypes = [vp, f32p, f32p, i64, i32, C.POINTER(Cost), i32, C.c_float, C.POINTER(SolveOptions), f32p, f32p,
+                               f32p, f32p, f32p, vp, f32p, f32p, f32p, vp]
+    lib.phnn_solve.restype = C.c_int
     lib.phnn_plant_step.argtypes = [vp, C.POINTER(Plant), vp, f32p, i64, i64, i32, C.c_float, C.c_float, f32p, vp, vp, i32,
                                     vp, f32p, vp]
     lib.phnn_plant_step.restype = C.c_int

@@ -19,6 +19,15 @@
 #include "../../include/phnn_mpc.h"
 
 #define DEV __device__ __forceinline__
+// The K1 -> K2 tape is streamed once each way at large batches: non-temporal stores / loads (worth 3 % each over plain
+// ones there).  PHNN_CACHED_TAPE (a translation-unit switch) uses plain accesses instead.
+#ifdef PHNN_CACHED_TAPE
+#define PHNN_NT_STORE(v, p) (*(p) = (v))
+#define PHNN_NT_LOAD(p) (*(p))
+#else
+#define PHNN_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define PHNN_NT_LOAD(p) __builtin_nontemporal_load((p))
+#endif
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -727,7 +736,7 @@ DEV f32x4 to4_rep(const float* Wt, Lane ln, const Act<TI>& in) {
 template <int T>
 DEV void store_act(float* dst, Lane ln, const Act<T>& a) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) __builtin_nontemporal_store(a.v[t], reinterpret_cast<f32x4*>(dst) + t * 64 + ln.lane);
+  for (int t = 0; t < T; ++t) PHNN_NT_STORE(a.v[t], reinterpret_cast<f32x4*>(dst) + t * 64 + ln.lane);
 }
 template <int T>
 DEV void load_act(const float* src, Lane ln, Act<T>& a) {
@@ -736,7 +745,7 @@ DEV void load_act(const float* src, Lane ln, Act<T>& a) {
 #ifdef PHNN_PLAIN_STASH_LOADS
     a.v[t] = reinterpret_cast<const f32x4*>(src)[t * 64 + ln.lane];
 #else
-    a.v[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + t * 64 + ln.lane);
+    a.v[t] = PHNN_NT_LOAD(reinterpret_cast<const f32x4*>(src) + t * 64 + ln.lane);
 #endif
   }
 }
@@ -760,14 +769,14 @@ DEV void store_act24(float* dst, Lane ln, const Act<T>& a) {
     u32x3 d = {__builtin_amdgcn_perm(q[1], q[0], 0x04020100u),   // q0.b0 q0.b1 q0.b2 q1.b0
                __builtin_amdgcn_perm(q[2], q[1], 0x05040201u),   // q1.b1 q1.b2 q2.b0 q2.b1
                __builtin_amdgcn_perm(q[3], q[2], 0x06050402u)};  // q2.b2 q3.b0 q3.b1 q3.b2
-    __builtin_nontemporal_store(d, reinterpret_cast<u32x3*>(reinterpret_cast<char*>(dst) + (t * 64 + ln.lane) * 12));
+    PHNN_NT_STORE(d, reinterpret_cast<u32x3*>(reinterpret_cast<char*>(dst) + (t * 64 + ln.lane) * 12));
   }
 }
 template <int T>
 DEV void load_act24(const float* src, Lane ln, Act<T>& a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const u32x3 d = __builtin_nontemporal_load(reinterpret_cast<const u32x3*>(reinterpret_cast<const char*>(src) + (t * 64 + ln.lane) * 12));
+    const u32x3 d = PHNN_NT_LOAD(reinterpret_cast<const u32x3*>(reinterpret_cast<const char*>(src) + (t * 64 + ln.lane) * 12));
     const int q0 = (int)(d[0] << 8) >> 8;
     const int q1 = (int)(__builtin_amdgcn_alignbit(d[1], d[0], 24) << 8) >> 8;
     const int q2 = (int)(__builtin_amdgcn_alignbit(d[2], d[1], 16) << 8) >> 8;
@@ -1239,13 +1248,13 @@ DEV void h1_bwd_operands(const float* L, Lane ln, const float (&obar)[16], f16x8
 // the 16 outputs of R_net per rollout in the K1 -> K2 tape: lane (i,q) keeps out[4q .. 4q+3] of rollout i (every lane
 // holds all 16 after gather16), one coalesced 1 KB store / load per wave
 DEV void store_rf(float* dst, Lane ln, f32x4 o) {  // o = outputs 4q .. 4q+3 of rollout i, as the output layer leaves them
-  if (ln.w == 0) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst) + ln.i * 4 + ln.q);
+  if (ln.w == 0) PHNN_NT_STORE(o, reinterpret_cast<f32x4*>(dst) + ln.i * 4 + ln.q);
 }
 DEV void load_rf(const float* src, Lane ln, float (&rf)[16]) {
   const f32x4* p = reinterpret_cast<const f32x4*>(src) + ln.i * 4;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    f32x4 v = __builtin_nontemporal_load(p + k);
+    f32x4 v = PHNN_NT_LOAD(p + k);
 #pragma unroll
     for (int e = 0; e < 4; ++e) rf[4 * k + e] = v[e];
   }
@@ -1399,7 +1408,7 @@ struct PhnnModel {
     if (ST) {
       store_act<T>(stash, ln, tp.a2);
       store_act<T>(stash + T * 256, ln, tp.q1);
-      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+      if (ln.q == 0) PHNN_NT_STORE(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
     }
     Act<T> hR;
     float rf[16];
@@ -1467,7 +1476,7 @@ struct PhnnModel {
     float rf[16];
     if (ST) {  // tape written by K1: the loads fly while a1 is recomputed and the R_net part below runs.  Loads return
       // in issue order (vmcnt): the small vectors the R_net part needs first are requested first, the big ones after
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      dH = PHNN_NT_LOAD(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       load_rf(stash + oStashRf, ln, rf);
       load_act<T>(stash, ln, tp.a2);
       load_act<T>(stash + T * 256, ln, tp.q1);
@@ -1698,7 +1707,7 @@ struct CanonModel {
       if (ST) {
         store_act<T>(stash, ln, tp.a2);
         store_act<T>(stash + T * 256, ln, tp.q1);
-        if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+        if (ln.q == 0) PHNN_NT_STORE(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
       }
       float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + Base_Gu(L, 2, u);
       float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + Base_Gu(L, 3, u);
@@ -1714,7 +1723,7 @@ struct CanonModel {
     if (ST) {
       store_act<T>(stash, ln, tp.a2);
       store_act<T>(stash + T * 256, ln, tp.q1);
-      if (ln.q == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+      if (ln.q == 0) PHNN_NT_STORE(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
     }
     float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + Base_Gu(L, 2, u);
     float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + Base_Gu(L, 3, u);
@@ -1745,7 +1754,7 @@ struct CanonModel {
       float Hdummy;
       f32x4 dH;
       if (ST) {
-        dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
+        dH = PHNN_NT_LOAD(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
         load_act<T>(stash, ln, tp.a2);
         load_act<T>(stash + T * 256, ln, tp.q1);
         hnet_layer1<HID, MM, ACT>(L + oH, ln, z, tp.a1);
@@ -1815,7 +1824,7 @@ struct CanonModel {
     float Hdummy;
     f32x4 dH;
     if (ST) {
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
+      dH = PHNN_NT_LOAD(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
       load_act<T>(stash, ln, tp.a2);
       load_act<T>(stash + T * 256, ln, tp.q1);
       hnet_layer1<HID, MM, ACT>(L + oH, ln, z, tp.a1);
@@ -2124,7 +2133,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
     }
     __syncthreads();
     f32x4 dH = xch_sum_partials(ln.xch + kXP0, ln);
-    if (ST && ln.q == 0 && ln.w == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+    if (ST && ln.q == 0 && ln.w == 0) PHNN_NT_STORE(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
     float G[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) G[i] = L[oG + i];
@@ -2143,7 +2152,7 @@ struct PhnnSplit {  // PhnnModel<N_, 128, fixed G, f16x2> with the tile split ov
     float rf[16];
     if (ST) {
       // small vectors first (vmcnt returns loads in issue order; the R_net part needs them first)
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
+      dH = PHNN_NT_LOAD(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);
       load_rf(stash + Base::oStashRf, ln, rf);  // R_net's outputs come with the tape: no fragment exchange, no barrier
       load_act<2>(stash + t0 * 256, ln, tp.a2);
       load_act<2>(stash + T * 256 + t0 * 256, ln, tp.q1);
@@ -2245,7 +2254,7 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
     }
     __syncthreads();
     f32x4 dH = xch_sum_partials(ln.xch + kXP0, ln);
-    if (ST && ln.q == 0 && ln.w == 0) __builtin_nontemporal_store(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
+    if (ST && ln.q == 0 && ln.w == 0) PHNN_NT_STORE(dH, reinterpret_cast<f32x4*>(stash + 2 * T * 256) + ln.i);
     float dp0 = (-dH[0] - L[oC + 6] * dH[2]) + Base_Gu(L, 2, u);
     float dp1 = (-dH[1] - L[oC + 7] * dH[3]) + Base_Gu(L, 3, u);
     float det = (a * c - bc * bc) + 1e-6f;
@@ -2268,7 +2277,7 @@ struct CanonSplit {  // CanonModel<128, f16x2> with the tile split over four wav
     HTapeW tp;
     f32x4 dH;
     if (ST) {
-      dH = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
+      dH = PHNN_NT_LOAD(reinterpret_cast<const f32x4*>(stash + 2 * T * 256) + ln.i);  // needed first: requested first
       load_act<2>(stash + t0 * 256, ln, tp.a2);
       load_act<2>(stash + T * 256 + t0 * 256, ln, tp.q1);
       using Y = LayH2<128, MM_F16X2>;
@@ -2659,36 +2668,48 @@ struct StashStep {
   static constexpr int FLOATS = INTEG == PHNN_INTEG_EULER ? M::STASH : 4 * SLOT;
 };
 DEV void store_stage(float* dst, Lane ln, f32x4 y) {  // ln.w: wave within a split tile (0 for whole-tile models)
-  if (ln.q == 0 && ln.w == 0) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(dst) + ln.i);
+  if (ln.q == 0 && ln.w == 0) PHNN_NT_STORE(y, reinterpret_cast<f32x4*>(dst) + ln.i);
 }
 DEV f32x4 load_stage(const float* src, Lane ln) {
-  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + ln.i);
+  return PHNN_NT_LOAD(reinterpret_cast<const f32x4*>(src) + ln.i);
 }
 
-// K1: forward march.  One wave = 16 rollouts; grid x = ceil(B/16/waves).
-template <class M, int INTEG, bool STASH>
-__global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int N = M::N;
-  stage_image<M::IMG>(lds, p.img);
+// Lane / tile bookkeeping shared by the march kernels.  One wave = 16 rollouts; split-tile models: the workgroup's four
+// waves share tile blockIdx.x (all four reach every barrier together).
+struct TileCtx {
+  Lane ln;
+  float* scr;
+  long long tile, b;
+  bool valid, writer;
+};
+template <class M>
+DEV bool tile_ctx(TileCtx& c, float* lds, long long B) {  // false: no tile for this wave
   const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   static_prio(wave);
-  Lane ln;
-  ln.lane = threadIdx.x & 63;
-  ln.i = ln.lane & 15;
-  ln.q = ln.lane >> 4;
-  ln.w = M::SPLIT ? wave : 0;
-  ln.xch = M::SPLIT ? lds + M::IMG + nwaves * M::SCR : nullptr;
-  float* scr = lds + M::IMG + wave * M::SCR;
-  // split-tile models: the workgroup's four waves share tile blockIdx.x (all four reach every barrier together)
-  const long long tile = M::SPLIT ? (long long)blockIdx.x : (long long)blockIdx.x * nwaves + wave;
-  if (tile * kTileB >= p.B) return;
-  long long b = tile * kTileB + ln.i;
-  const bool valid = b < p.B;
-  if (!valid) b = p.B - 1;
-  const float* L = lds;
+  c.ln.lane = threadIdx.x & 63;
+  c.ln.i = c.ln.lane & 15;
+  c.ln.q = c.ln.lane >> 4;
+  c.ln.w = M::SPLIT ? wave : 0;
+  c.ln.xch = M::SPLIT ? lds + M::IMG + nwaves * M::SCR : nullptr;
+  c.scr = lds + M::IMG + wave * M::SCR;
+  c.tile = M::SPLIT ? (long long)blockIdx.x : (long long)blockIdx.x * nwaves + wave;
+  if (c.tile * kTileB >= B) return false;
+  c.b = c.tile * kTileB + c.ln.i;
+  c.valid = c.b < B;
+  if (!c.valid) c.b = B - 1;
+  c.writer = c.valid && c.ln.q == 0 && (!M::SPLIT || wave == 0);
+  return true;
+}
+
+// K1: forward march of one tile.
+template <class M, int INTEG, bool STASH>
+DEV void fwd_march(const RollParams& p, const float* L, const TileCtx& tc) {
+  constexpr int N = M::N;
+  const Lane ln = tc.ln;
+  float* scr = tc.scr;
+  const long long tile = tc.tile, b = tc.b;
+  const bool writer = tc.writer;
   f32x4 x = load_state<N>(p.x0 + b * N);
-  const bool writer = valid && ln.q == 0 && (!M::SPLIT || wave == 0);
   if (p.traj && writer) store_state<N>(p.traj + (b * (p.H + 1)) * N, x);
   float cost = state_cost<N>(p.c, x);
   constexpr int MI = M::MI;
@@ -2724,29 +2745,24 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
   if (writer && p.cost) p.cost[b] = cost;
 }
 
+template <class M, int INTEG, bool STASH>
+__global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_fwd(RollParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_image<M::IMG>(lds, p.img);
+  TileCtx tc;
+  if (!tile_ctx<M>(tc, lds, p.B)) return;
+  fwd_march<M, INTEG, STASH>(p, lds, tc);
+}
+
 // K2: adjoint march over the states K1 stored.  WG: every dynamics VJP also emits its weight-gradient record
 // (training side: k_wgrad_reduce sums them into d loss / d theta).
 template <class M, int INTEG, bool STASH, bool WG = false>
-__global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+DEV void grad_march(const RollParams& p, const float* L, const TileCtx& tc) {
   constexpr int N = M::N;
-  stage_image<M::IMG>(lds, p.img);
-  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  static_prio(wave);
-  Lane ln;
-  ln.lane = threadIdx.x & 63;
-  ln.i = ln.lane & 15;
-  ln.q = ln.lane >> 4;
-  ln.w = M::SPLIT ? wave : 0;
-  ln.xch = M::SPLIT ? lds + M::IMG + nwaves * M::SCR : nullptr;
-  float* scr = lds + M::IMG + wave * M::SCR;
-  const long long tile = M::SPLIT ? (long long)blockIdx.x : (long long)blockIdx.x * nwaves + wave;
-  if (tile * kTileB >= p.B) return;
-  long long b = tile * kTileB + ln.i;
-  const bool valid = b < p.B;
-  if (!valid) b = p.B - 1;
-  const float* L = lds;
-  const bool writer = valid && ln.q == 0 && (!M::SPLIT || wave == 0);
+  const Lane ln = tc.ln;
+  float* scr = tc.scr;
+  const long long tile = tc.tile, b = tc.b;
+  const bool valid = tc.valid, writer = tc.writer;
   const float* tr = p.traj_in + (b * (p.H + 1)) * N;
   constexpr int MI = M::MI;
   const float* up = p.u + b * p.H * MI;
@@ -2842,6 +2858,20 @@ __global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
   }
   if (p.grad_x0 && writer) store_state<N>(p.grad_x0 + b * N, lam);
 }
+
+template <class M, int INTEG, bool STASH, bool WG = false>
+__global__ __launch_bounds__(64 * kMaxWaves) void k_rollout_grad(RollParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_image<M::IMG>(lds, p.img);
+  TileCtx tc;
+  if (!tile_ctx<M>(tc, lds, p.B)) return;
+  grad_march<M, INTEG, STASH, WG>(p, lds, tc);
+}
+
+// (Measured, round 3, and removed: a fused solve kernel -- `iters` x (forward march, adjoint march, Adam step) for one
+// tile inside one workgroup, one launch instead of 3 x iters, the image staged once.  Bit-identical results, but a
+// single-plant solve took 3.54 ms against 3.48 ms as separate launches: back-to-back launches on one stream are already
+// pipelined, the solve is the serial chain of its time steps and nothing else.  fwd_march / grad_march stay factored out.)
 
 // model(x,u) -> (dx, H)
 template <class M>

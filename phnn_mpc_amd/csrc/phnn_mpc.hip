@@ -1041,6 +1041,44 @@ int phnn_adam_step(phnn_handle* h, float* u_dev, const float* grad_dev, float* e
   return PHNN_OK;
 }
 
+int phnn_solve(phnn_handle* h, const float* x0_dev, float* u_dev, int64_t B, int32_t H, const phnn_cost* cost,
+               int32_t integrator, float dt, const phnn_solve_options* opt, float* exp_avg_dev, float* exp_avg_sq_dev,
+               float* grad_dev, float* cost_dev, float* traj_dev, void* workspace_dev, float* costs_dev,
+               float* best_cost_dev, float* best_u_dev, void* stream) {
+  if (!h) return PHNN_ERR_INVALID_ARG;
+  if (!opt || opt->iters < 0) return fail(h, PHNN_ERR_INVALID_ARG, "phnn_solve_options: NULL or iters < 0");
+  RollParams p;
+  if (int rc = fill_roll(h, &p, x0_dev, u_dev, B, H, cost, integrator, dt)) return rc;
+  if (B == 0 || opt->iters == 0) return PHNN_OK;
+  if (!exp_avg_dev || !exp_avg_sq_dev || !grad_dev || !cost_dev || !traj_dev)
+    return fail(h, PHNN_ERR_INVALID_ARG, "phnn_solve: exp_avg, exp_avg_sq, grad, cost and traj buffers are required");
+  if (opt->track_best && (!best_cost_dev || !best_u_dev)) return fail(h, PHNN_ERR_INVALID_ARG, "track_best needs best_cost_dev and best_u_dev");
+  PHNN_ON_DEVICE(h);
+  hipStream_t st = (hipStream_t)stream;
+  const int m = h->desc.m;
+  const size_t count = (size_t)B * H * m;
+  // fresh optimizer state (torch.optim.Adam created per solve, src/mpc_controller.py:168), best = +inf
+  hipError_t e = hipMemsetAsync(exp_avg_dev, 0, sizeof(float) * count, st);
+  if (e == hipSuccess) e = hipMemsetAsync(exp_avg_sq_dev, 0, sizeof(float) * count, st);
+  if (e == hipSuccess && opt->track_best) e = hipMemsetD32Async((hipDeviceptr_t)best_cost_dev, 0x7F800000, (size_t)B, st);
+  if (e == hipSuccess && opt->track_best) e = hipMemsetAsync(best_u_dev, 0, sizeof(float) * count, st);
+  if (e != hipSuccess) return hip_fail(h, e, "phnn_solve: state reset");
+  for (int k = 0; k < opt->iters; ++k) {
+    if (int rc = phnn_rollout_fwd(h, x0_dev, u_dev, B, H, cost, integrator, dt, cost_dev, traj_dev, workspace_dev, stream)) return rc;
+    if (costs_dev) {
+      e = hipMemcpyAsync(costs_dev + (size_t)k * B, cost_dev, sizeof(float) * (size_t)B, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return hip_fail(h, e, "phnn_solve: cost history copy");
+    }
+    if (int rc = phnn_rollout_grad(h, x0_dev, u_dev, B, H, cost, integrator, dt, traj_dev, workspace_dev, grad_dev, nullptr, stream)) return rc;
+    if (int rc = phnn_adam_step(h, u_dev, grad_dev, exp_avg_dev, exp_avg_sq_dev, (int64_t)count, opt->lr, opt->beta1, opt->beta2,
+                                opt->eps, k + 1, opt->track_best ? cost_dev : nullptr, opt->track_best ? best_cost_dev : nullptr,
+                                opt->track_best ? best_u_dev : nullptr, (int64_t)H * m, cost->u_min, cost->u_max,
+                                cost->has_u_bounds, stream))
+      return rc;
+  }
+  return PHNN_OK;
+}
+
 int phnn_plant_step(phnn_handle* h, const phnn_plant* plant, double* state_dev, const float* action_dev,
                     int64_t action_stride, int64_t B, int32_t has_u_bounds, float u_min, float u_max,
                     float* state_f32_dev, int32_t* done_step_dev, const int32_t* step_dev, int32_t step_host,

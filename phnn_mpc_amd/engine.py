@@ -364,6 +364,43 @@ class RolloutEngine:
                                      self._stream())
         _check(self.lib, self.h, rc)
 
+    # ------------------------------------------------------------------ the whole shooting solve (K1, K2, K3 x iters)
+    def solve(self, x0, u_init, cost, integrator="euler", dt=0.02, lr=0.015, iters=30, track_best=False, record_costs=True,
+              beta1=0.9, beta2=0.999, eps=1e-8, workspace=None):
+        """phnn_solve: Adam on the control sequences of B independent problems, the loops of
+        src/mpc_controller.py:164-209 / src/mpc_controller_canonical.py:163-228, as ONE library call that enqueues the
+        K1 / K2 / K3 launches of every iteration (no Python between them).  -> dict as solver.shooting_solve, same
+        results bit for bit."""
+        x0 = self._t(x0, (-1, self.n))
+        B = x0.shape[0]
+        u_init, H = self._controls(u_init, B)
+        integ = self._integ(integrator)
+        ws = workspace if workspace is not None else {}
+        key = ("solve", B, H, integ, int(iters))
+        if ws.get("skey") != key:
+            ws["skey"] = key
+            nbytes = self.workspace_bytes(B, H, integ) if self.use_stash else 0
+            ws["s_stash"] = (torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                             if 0 < nbytes <= self.max_stash_bytes else None)
+            f = dict(dtype=torch.float32, device=self.device)
+            ws["s_traj"], ws["s_cost"] = torch.empty(B, H + 1, self.n, **f), torch.empty(B, **f)
+            ws["s_grad"], ws["s_m"], ws["s_v"] = (torch.empty(B, H, self.m, **f) for _ in range(3))
+        u = u_init.detach().clone().contiguous()
+        f = dict(dtype=torch.float32, device=self.device)
+        costs = torch.empty(int(iters), B, **f) if record_costs else None
+        best_cost = torch.empty(B, **f) if track_best else None
+        best_u = torch.empty(B, H, self.m, **f) if track_best else None
+        opt = _capi.SolveOptions(int(iters), float(lr), float(beta1), float(beta2), float(eps), int(bool(track_best)))
+        rc = self.lib.phnn_solve(self.h, self._p(x0), self._p(u), B, H, C.byref(cost), integ, float(dt), C.byref(opt),
+                                 self._p(ws["s_m"]), self._p(ws["s_v"]), self._p(ws["s_grad"]), self._p(ws["s_cost"]),
+                                 self._p(ws["s_traj"]), self._p(ws["s_stash"]), self._p(costs), self._p(best_cost),
+                                 self._p(best_u), self._stream())
+        _check(self.lib, self.h, rc)
+        out = {"u_last": u, "costs": costs}
+        if track_best:
+            out["best_u"], out["best_cost"] = best_u, best_cost
+        return out
+
     # ------------------------------------------------------------------ the plant, on the device (SURVEY 8 f3)
     def plant_step(self, plant, state, action, action_stride, u_min=None, u_max=None, state_f32=None, done_step=None,
                    step=0, step_dev=None, log_states=None, log_controls=None):

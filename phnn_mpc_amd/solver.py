@@ -44,8 +44,17 @@ def shooting_solve(engine, x0, u_init, cost, integrator, dt, lr, iters, track_be
     return out
 
 
-def _eager(engine, *args, **kw):
-    return shooting_solve(engine, *args, **kw)
+def _eager(engine, x0, u_init, cost, integrator, dt, lr, iters, track_best=False, u_min=None, u_max=None, record_costs=True):
+    """The solve without a captured graph: the library's own loop (phnn_solve: one call enqueues every launch) when the
+    engine has one and the Adam-side bounds are the cost's (they are for both controller classes); else the Python loop.
+    Same launches, same order: identical results."""
+    has_b = u_min is not None and u_max is not None
+    same = bool(cost.has_u_bounds) == has_b and (not has_b or (float(cost.u_min) == float(ctypes.c_float(u_min).value)
+                                                                and float(cost.u_max) == float(ctypes.c_float(u_max).value)))
+    if hasattr(engine, "solve") and same:
+        return engine.solve(x0, u_init, cost, integrator, dt, lr=lr, iters=iters, track_best=track_best, record_costs=record_costs)
+    return shooting_solve(engine, x0, u_init, cost, integrator, dt, lr, iters, track_best=track_best, u_min=u_min, u_max=u_max,
+                          record_costs=record_costs)
 
 
 def solver_for(engine, use_graph, previous=None):

@@ -28,3 +28,14 @@ for mode in ("never", "always"):
             solve(*args, **kw)
         torch.cuda.synchronize()
         print(f"split={mode:6s} {label}: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per solve", flush=True)
+# the same solve through phnn_solve (one C call enqueues the 90 launches)
+eng = RolloutEngine(w)
+ws = {}
+for _ in range(3):
+    eng.solve(x0, u0, cost, "euler", 0.02, lr=0.015, iters=30, record_costs=False, workspace=ws)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    eng.solve(x0, u0, cost, "euler", 0.02, lr=0.015, iters=30, record_costs=False, workspace=ws)
+torch.cuda.synchronize()
+print(f"phnn_solve            : {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per solve", flush=True)
