@@ -3361,6 +3361,8 @@ __global__ __launch_bounds__(64 * M::T) void k_wgrad_reduce(WgradParams p) {
     }
   };
   const long long G = gridDim.x, last = p.n_rec - 1;
+  // PHNN_WG_DEBUG_{CACHED,NOGEMM,NOSTAGE,NOBARRIER}: timing diagnostics only (wrong results) -- the record stream served
+  // from L2, the loop without its GEMM phase / element-wise stage / barrier: profiles/r03_wgrad_reduce_diagnostics.txt
 #ifdef PHNN_WG_DEBUG_CACHED
   auto slice_of = [&](long long r) { return p.rec + ((r < last ? r : last) & 255) * Rec::SIZE; };
   auto tape_of = [&](long long r) { return TAPES ? p.tapes + ((r < last ? r : last) & 255) * (long long)p.tape_stride : nullptr; };
