@@ -30,7 +30,7 @@ extern "C" {
 
 #define PHNN_MAX_N 8      /* state dimension limit (array bound of the structs below)  */
 #define PHNN_MAX_M 4      /* array bound for R in phnn_cost; see PHNN_SUPPORTED_M        */
-#define PHNN_SUPPORTED_M 2 /* largest input dimension with gfx950 kernels (m = 2: pHNN n = 4 and canonical pHNN); phnn_create refuses more */
+#define PHNN_SUPPORTED_M 4 /* largest input dimension with gfx950 kernels (m = 2..4: pHNN n = 4 and canonical cart-pole pHNN); phnn_create refuses more */
 #define PHNN_MAX_LAYERS 4 /* hidden layers per MLP  */
 
 typedef enum {

@@ -176,15 +176,19 @@ int pick_variant(const phnn_desc* d, const phnn_options& opt, std::string* why) 
     *why = buf;
     return V_NONE;
   }
-  if (d->m == 2) {  // two controls: 128-wide f16x2 kernels of the cart-pole-sized models (n = 4); narrower nets are zero-padded
+  if (d->m >= 2) {  // two to four controls: 128-wide f16x2 kernels of the cart-pole-sized models (n = 4); narrower nets are zero-padded
     const int hid = d->h_net.hidden[0];
     const bool f16 = matmul_mode(opt, 128) == MM_F16X2;
+    static const int fix_v[3] = {V_PHNN_4_128_FIX_H_M2, V_PHNN_4_128_FIX_H_M3, V_PHNN_4_128_FIX_H_M4};
+    static const int gnet_v[3] = {V_PHNN_4_128_GNET_H_M2, V_PHNN_4_128_GNET_H_M3, V_PHNN_4_128_GNET_H_M4};
+    static const int canon_v[3] = {V_CANON_128_H_M2, V_CANON_128_H_M3, V_CANON_128_H_M4};
     if (f16 && d->kind == PHNN_MODEL_PHNN && d->n == 4 && hid == 128 && same_hidden(d->h_net, 2, 128) &&
         same_hidden(d->r_net, 1, 128) && (d->fixed_G || same_hidden(d->g_net, 1, 128)))
-      return d->fixed_G ? V_PHNN_4_128_FIX_H_M2 : V_PHNN_4_128_GNET_H_M2;
-    if (f16 && d->kind == PHNN_MODEL_CANONICAL && d->n == 4 && same_hidden(d->h_net, 2, 128)) return V_CANON_128_H_M2;
-    *why = "input_dim m=2: kernels exist for the pHNN (n=4, fixed or learned G) and the canonical pHNN, hidden widths up "
-           "to 128, f16x2 products";
+      return (d->fixed_G ? fix_v : gnet_v)[d->m - 2];
+    if (f16 && d->kind == PHNN_MODEL_CANONICAL && d->mass_type == PHNN_MASS_CARTPOLE && d->n == 4 && same_hidden(d->h_net, 2, 128))
+      return canon_v[d->m - 2];
+    *why = "input_dim m = 2..4: kernels exist for the pHNN (n=4, fixed or learned G) and the canonical cart-pole pHNN, hidden "
+           "widths up to 128, f16x2 products";
     return V_NONE;
   }
   if (d->kind == PHNN_MODEL_PHNN) {
@@ -294,7 +298,7 @@ bool pad_model(const phnn_desc* d, const float* blob, phnn_desc* pd, std::vector
   if (d->kind == PHNN_MODEL_PHNN) W = (mx <= 64 && (d->fixed_G || d->n == 2)) ? 64 : 128;
   else if (d->kind == PHNN_MODEL_CANONICAL) W = mx <= 64 ? 64 : 128;
   else W = (d->n == 2 && mx <= 64) ? 64 : 128;
-  if (d->m > 1) W = 128;  // the m = 2 kernels exist at width 128 only
+  if (d->m > 1) W = 128;  // the m >= 2 kernels exist at width 128 only
   if (d->activation != PHNN_ACT_TANH) W = 128;  // so do the SiLU / ReLU / ELU / GELU ones
   if (d->kind == PHNN_MODEL_CANONICAL && d->mass_type != PHNN_MASS_CARTPOLE) W = 128;  // so do the MassMatrixNetwork ones
   if (mx > W || mx < 1) {

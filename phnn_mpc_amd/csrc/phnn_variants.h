@@ -33,6 +33,12 @@ enum Variant {
   V_PHNN_4_128_FIX_H_M2,   // two controls per step (m = 2): G is (n, 2), u is (B, H, 2)
   V_PHNN_4_128_GNET_H_M2,
   V_CANON_128_H_M2,
+  V_PHNN_4_128_FIX_H_M3,   // three and four controls per step
+  V_PHNN_4_128_GNET_H_M3,
+  V_CANON_128_H_M3,
+  V_PHNN_4_128_FIX_H_M4,
+  V_PHNN_4_128_GNET_H_M4,
+  V_CANON_128_H_M4,
   V_CANON_128_H_MCONST,  // canonical pHNN with MassMatrixNetwork 'constant' / 'diagonal' / 'full' (src/mass_matrix.py:15-216)
   V_CANON_128_H_MDIAG,
   V_CANON_128_H_MFULL,
@@ -79,6 +85,12 @@ using M_ODE_2_64_H = OdeModel<2, 64, MM_F16X2>;
 using M_PHNN_4_128_FIX_H_M2 = PhnnModel<4, 128, true, MM_F16X2, 2>;
 using M_PHNN_4_128_GNET_H_M2 = PhnnModel<4, 128, false, MM_F16X2, 2>;
 using M_CANON_128_H_M2 = CanonModel<128, MM_F16X2, 2>;
+using M_PHNN_4_128_FIX_H_M3 = PhnnModel<4, 128, true, MM_F16X2, 3>;
+using M_PHNN_4_128_GNET_H_M3 = PhnnModel<4, 128, false, MM_F16X2, 3>;
+using M_CANON_128_H_M3 = CanonModel<128, MM_F16X2, 3>;
+using M_PHNN_4_128_FIX_H_M4 = PhnnModel<4, 128, true, MM_F16X2, 4>;
+using M_PHNN_4_128_GNET_H_M4 = PhnnModel<4, 128, false, MM_F16X2, 4>;
+using M_CANON_128_H_M4 = CanonModel<128, MM_F16X2, 4>;
 using M_CANON_128_H_MCONST = CanonModel<128, MM_F16X2, 1, MASS_CONSTANT>;
 using M_CANON_128_H_MDIAG = CanonModel<128, MM_F16X2, 1, MASS_DIAGONAL>;
 using M_CANON_128_H_MFULL = CanonModel<128, MM_F16X2, 1, MASS_FULL>;
@@ -165,6 +177,12 @@ hipError_t phnn_wgrad_finish(const float* slab, int rows, int PP, const int* map
   X(V_PHNN_4_128_FIX_H_M2, M_PHNN_4_128_FIX_H_M2, "phnn<n=4,m=2,hid=128,fixedG,f16x2>") \
   X(V_PHNN_4_128_GNET_H_M2, M_PHNN_4_128_GNET_H_M2, "phnn<n=4,m=2,hid=128,Gnet,f16x2>") \
   X(V_CANON_128_H_M2, M_CANON_128_H_M2, "canonical<m=2,hid=128,f16x2>") \
+  X(V_PHNN_4_128_FIX_H_M3, M_PHNN_4_128_FIX_H_M3, "phnn<n=4,m=3,hid=128,fixedG,f16x2>") \
+  X(V_PHNN_4_128_GNET_H_M3, M_PHNN_4_128_GNET_H_M3, "phnn<n=4,m=3,hid=128,Gnet,f16x2>") \
+  X(V_CANON_128_H_M3, M_CANON_128_H_M3, "canonical<m=3,hid=128,f16x2>") \
+  X(V_PHNN_4_128_FIX_H_M4, M_PHNN_4_128_FIX_H_M4, "phnn<n=4,m=4,hid=128,fixedG,f16x2>") \
+  X(V_PHNN_4_128_GNET_H_M4, M_PHNN_4_128_GNET_H_M4, "phnn<n=4,m=4,hid=128,Gnet,f16x2>") \
+  X(V_CANON_128_H_M4, M_CANON_128_H_M4, "canonical<m=4,hid=128,f16x2>") \
   X(V_CANON_128_H_MCONST, M_CANON_128_H_MCONST, "canonical<hid=128,f16x2,mass=constant>") \
   X(V_CANON_128_H_MDIAG, M_CANON_128_H_MDIAG, "canonical<hid=128,f16x2,mass=diagonal>") \
   X(V_CANON_128_H_MFULL, M_CANON_128_H_MFULL, "canonical<hid=128,f16x2,mass=full>") \

@@ -44,6 +44,12 @@ bool phnn_wgrad_kernels(int variant, WgradSet* g) {
     PHNN_WCASE(V_PHNN_4_128_FIX_H_M2, M_PHNN_4_128_FIX_H_M2)
     PHNN_WCASE(V_PHNN_4_128_GNET_H_M2, M_PHNN_4_128_GNET_H_M2)
     PHNN_WCASE(V_CANON_128_H_M2, M_CANON_128_H_M2)
+    PHNN_WCASE(V_PHNN_4_128_FIX_H_M3, M_PHNN_4_128_FIX_H_M3)
+    PHNN_WCASE(V_PHNN_4_128_GNET_H_M3, M_PHNN_4_128_GNET_H_M3)
+    PHNN_WCASE(V_CANON_128_H_M3, M_CANON_128_H_M3)
+    PHNN_WCASE(V_PHNN_4_128_FIX_H_M4, M_PHNN_4_128_FIX_H_M4)
+    PHNN_WCASE(V_PHNN_4_128_GNET_H_M4, M_PHNN_4_128_GNET_H_M4)
+    PHNN_WCASE(V_CANON_128_H_M4, M_CANON_128_H_M4)
     PHNN_WCASE(V_CANON_128_H_MCONST, M_CANON_128_H_MCONST)
     PHNN_WCASE(V_CANON_128_H_MDIAG, M_CANON_128_H_MDIAG)
     PHNN_WCASE(V_CANON_128_H_MFULL, M_CANON_128_H_MFULL)

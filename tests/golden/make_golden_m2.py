@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Golden vectors for models with TWO control inputs (m = 2), produced by running the REFERENCE.
+"""Golden vectors for models with TWO (golden_m2.npz) and THREE / FOUR (golden_m34.npz) control inputs,
+produced by running the REFERENCE.
 
 Build container only (reference mounted read-only at /root/reference).  Constructs the reference's own pHNN (fixed G and
 learned G_net, src/pHNN.py:31-38,86-92) and pHNN_Canonical with input_dim = 2 from temporary YAML files (the shipped
@@ -34,11 +35,15 @@ import integrators  # noqa: E402
 torch.set_num_threads(1)
 
 
-def build(cls, seed, fixed_G):
+G4 = [[0.0, 0.3, -0.2, 0.1], [0.2, 0.0, 0.4, -0.3], [1.0, -0.5, 0.25, 0.6], [0.0, 0.8, -0.7, 0.35]]
+R4 = np.array([[0.02, 0.004, 0.0, -0.001], [-0.002, 0.05, 0.003, 0.0], [0.001, 0.0, 0.03, 0.002], [0.0, -0.004, 0.001, 0.04]], np.float32)
+
+
+def build(cls, seed, fixed_G, m=2):
     cfg = yaml.safe_load(open("cartpole_mpc_config.yaml"))
-    cfg["model"]["input_dim"] = 2
+    cfg["model"]["input_dim"] = m
     cfg["model"]["fixed_G"] = fixed_G
-    cfg["model"]["G_value"] = [[0.0, 0.3], [0.2, 0.0], [1.0, -0.5], [0.0, 0.8]]
+    cfg["model"]["G_value"] = [row[:m] for row in G4]
     cfg["model"]["G_mlp"] = {"activation": "nn.Tanh", "bias": True, "dropout": 0.0, "hidden_sizes": [128], "layer_norm": False}
     with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as tf:
         yaml.safe_dump(cfg, tf)
@@ -48,9 +53,9 @@ def build(cls, seed, fixed_G):
     return m
 
 
-def block(name, model, out, seed):
+def block(name, model, out, seed, m=2):
     rng = np.random.default_rng(seed)
-    n, m, dt = 4, 2, 0.02
+    n, dt = 4, 0.02
     for k, v in model.state_dict().items():
         out[f"w/{name}/{k}"] = v.detach().numpy().copy()
     xlo = np.array([-1.0, -0.3, -0.5, -0.5])
@@ -76,8 +81,10 @@ def block(name, model, out, seed):
     x0 = rng.uniform(xlo, -xlo, size=(B, n)).astype(np.float32)
     U = rng.uniform(-12, 12, size=(B, H, m)).astype(np.float32)
     U[0, 1, 0], U[0, 1, 1], U[1, 4, 1], U[2, 0, 0] = 13.0, -11.0, 10.0, -10.0  # outside / on the clamp bounds +-10
+    if m > 2:
+        U[3, 2, m - 1] = -14.0
     Q = np.diag([10.0, 200.0, 1.0, 10.0]).astype(np.float32)
-    R = np.array([[0.02, 0.004], [-0.002, 0.05]], np.float32)
+    R = np.ascontiguousarray(R4[:m, :m])
     out[f"{name}/roll_x0"], out[f"{name}/roll_U"], out[f"{name}/Q"], out[f"{name}/R"] = x0, U, Q, R
     for integ in ("euler", "rk4"):
         y0 = torch.tensor(x0, dtype=torch.float64, requires_grad=True)
@@ -104,6 +111,19 @@ def main():
     block("canonical_m2", can, out, 2103)
     np.savez(os.path.join(OUT, "golden_m2.npz"), **out)
     print("wrote golden_m2.npz:", len(out), "arrays,", sum(v.nbytes for v in out.values()) // 1024, "KiB")
+    # three and four control inputs (golden_m34.npz): one model of each family
+    out = {}
+    block("phnn_m3_fix", build(pHNN, 31, True, 3), out, 3101, 3)
+    block("phnn_m4_gnet", build(pHNN, 32, False, 4), out, 3102, 4)
+    can = build(pHNN_Canonical, 33, True, 3)
+    with torch.no_grad():
+        can.M_net.log_a.fill_(0.25)
+        can.M_net.b.fill_(0.30)
+        can.M_net.log_c.fill_(-0.15)
+        can.R_diag_raw.copy_(torch.tensor([0.2, -0.3, 0.6, 0.15]))
+    block("canonical_m3", can, out, 3103, 3)
+    np.savez(os.path.join(OUT, "golden_m34.npz"), **out)
+    print("wrote golden_m34.npz:", len(out), "arrays,", sum(v.nbytes for v in out.values()) // 1024, "KiB")
 
 
 if __name__ == "__main__":

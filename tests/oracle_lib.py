@@ -194,6 +194,10 @@ def load_m2_golden():
 
 
 M2_MODELS = ["phnn_m2_fix", "phnn_m2_gnet", "canonical_m2"]
+# models with two, three and four control inputs: (golden file, model name, m)
+MULTI_INPUT_MODELS = [("golden_m2.npz", n, 2) for n in M2_MODELS] + [("golden_m34.npz", "phnn_m3_fix", 3),
+                                                                      ("golden_m34.npz", "phnn_m4_gnet", 4),
+                                                                      ("golden_m34.npz", "canonical_m3", 3)]
 # models with other activations than Tanh (tests/golden/make_golden_act.py): name -> activation
 ACT_MODELS = {"phnn_silu": "silu", "phnn_relu": "relu", "canonical_silu": "silu", "odefunc_relu": "relu",
               "phnn_elu": "elu", "phnn_gelu": "gelu", "canonical_elu": "elu", "canonical_gelu": "gelu",

@@ -322,24 +322,25 @@ def test_training_loop_descends_and_weights_refresh(torch, wg):
 
 
 # ----------------------------------------------------------------------------- two control inputs (m = 2), row f2
-@pytest.mark.parametrize("name", ol.M2_MODELS)
-def test_two_inputs_m2_vs_reference(torch, name):
-    """Models with input_dim = 2 (G is (n,2), controls (B,H,2), full 2x2 control weight): model(x,u), VJP, Euler and
-    RK4 rollouts with cost and gradients, parameter gradients -- against the reference's own outputs (golden_m2.npz)."""
+@pytest.mark.parametrize("fname,name,m", ol.MULTI_INPUT_MODELS)
+def test_several_inputs_vs_reference(torch, fname, name, m):
+    """Models with input_dim = 2, 3, 4 (G is (n,m), controls (B,H,m), full m x m control weight): model(x,u), VJP, Euler
+    and RK4 rollouts with cost and gradients, parameter gradients -- against the reference's own outputs
+    (golden_m2.npz, golden_m34.npz)."""
     from phnn_mpc_amd import _capi
     from phnn_mpc_amd.engine import RolloutEngine
-    g, ws = ol.load_m2_golden()
+    g, ws = ol.load_named_golden(fname)
     w = ws[name]
     eng = RolloutEngine(w)
-    assert (eng.n, eng.m) == (4, 2) and "m=2" in eng.variant
+    assert (eng.n, eng.m) == (4, m) and f"m={m}" in eng.variant
     dx, H = eng.forward(g[f"{name}/x"], g[f"{name}/u"])
     assert np.abs(npy(dx) - g[f"{name}/fwd_dx"]).max() <= 2e-5 * np.abs(g[f"{name}/fwd_dx"]).max()
     assert np.abs(npy(H) - g[f"{name}/fwd_H"]).max() <= 2e-5 * max(1.0, np.abs(g[f"{name}/fwd_H"]).max())
     xb, ub = eng.vjp(g[f"{name}/x"], g[f"{name}/u"], g[f"{name}/lam"])
-    assert ub.shape == (64, 2)
+    assert ub.shape == (64, m)
     assert np.abs(npy(xb) - g[f"{name}/vjp_xbar"]).max() <= 2e-5 * np.abs(g[f"{name}/vjp_xbar"]).max()
     assert np.abs(npy(ub) - g[f"{name}/vjp_ubar"]).max() <= 2e-5 * np.abs(g[f"{name}/vjp_ubar"]).max()
-    cost = _capi.make_cost(4, 2, g[f"{name}/Q"], g[f"{name}/R"], None, -10.0, 10.0)
+    cost = _capi.make_cost(4, m, g[f"{name}/Q"], g[f"{name}/R"], None, -10.0, 10.0)
     U = g[f"{name}/roll_U"]
     for integ in ("euler", "rk4"):
         c, gu, gx = eng.rollout_cost_grad(g[f"{name}/roll_x0"], U, cost, integ, 0.02, want_grad_x0=True)
@@ -347,7 +348,7 @@ def test_two_inputs_m2_vs_reference(torch, name):
         assert np.allclose(npy(c), g[f"{name}/roll_{integ}_cost"], rtol=1e-5)
         assert np.allclose(npy(traj), g[f"{name}/roll_{integ}_traj"], rtol=1e-5, atol=1e-5)
         rgu = g[f"{name}/roll_{integ}_gu"]
-        assert gu.shape == (6, 30, 2)
+        assert gu.shape == (6, 30, m)
         gmax = np.abs(rgu).max(axis=(1, 2), keepdims=True)
         assert np.all(np.abs(npy(gu) - rgu) <= 1e-4 * gmax), (np.abs(npy(gu) - rgu) / gmax).max()
         rgx = g[f"{name}/roll_{integ}_gx0"]
@@ -360,12 +361,18 @@ def test_two_inputs_m2_vs_reference(torch, name):
     m64 = ol.OracleModel(w, "f64")
     rng = np.random.default_rng(5)
     x0 = (rng.uniform(-1, 1, size=(150, 4)) * [1.0, 0.3, 0.5, 0.5]).astype(np.float32)
-    U2 = rng.uniform(-11, 11, size=(150, 20, 2)).astype(np.float32)
+    U2 = rng.uniform(-11, 11, size=(150, 20, m)).astype(np.float32)
     ref = m64.rollout(x0, U2, cost, "euler", 0.02, nthreads=8)
     c, gu = eng.rollout_cost_grad(x0, U2, cost, "euler", 0.02)
     assert np.allclose(npy(c), ref["cost"], rtol=1e-5)
     assert np.all(np.abs(npy(gu) - ref["grad_u"]) <= 1e-4 * np.abs(ref["grad_u"]).max(axis=(1, 2), keepdims=True))
-    print(f"{name}: m=2 parity ok, worst parameter-gradient tensor error {worst:.2e}")
+    print(f"{name}: m={m} parity ok, worst parameter-gradient tensor error {worst:.2e}")
+    # the Adam solve on (B,H,m) controls: the library's loop against the Python loop
+    from phnn_mpc_amd.solver import shooting_solve
+    x0t, u0t = torch.tensor(x0[:40], device=eng.device), torch.tensor(0.1 * U2[:40], device=eng.device)
+    ref_s = shooting_solve(eng, x0t, u0t, cost, "euler", 0.02, 0.02, 5, track_best=True, u_min=-10.0, u_max=10.0)
+    out_s = eng.solve(x0t, u0t, cost, "euler", 0.02, lr=0.02, iters=5, track_best=True)
+    assert torch.equal(out_s["u_last"], ref_s["u_last"]) and torch.equal(out_s["best_u"], ref_s["best_u"])
 
 
 # ----------------------------------------------------------------------------- MassMatrixNetwork (row f2)

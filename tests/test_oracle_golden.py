@@ -203,25 +203,25 @@ def test_oracle_rollout_wgrad_g16(wg, name, integ):
 
 
 # ----------------------------------------------------------------------------- two control inputs (m = 2), row f2
-@pytest.mark.parametrize("name", ol.M2_MODELS)
-def test_oracle_two_inputs_m2(name):
+@pytest.mark.parametrize("fname,name,nu", ol.MULTI_INPUT_MODELS)
+def test_oracle_several_inputs(fname, name, nu):
     from phnn_mpc_amd import _capi, weights
-    g, ws = ol.load_m2_golden()
+    g, ws = ol.load_named_golden(fname)
     w = ws[name]
     m = ol.OracleModel(w, "f64")
-    assert (m.n, m.m) == (4, 2)
+    assert (m.n, m.m) == (4, nu)
     dx, H = m.forward(g[f"{name}/x"], g[f"{name}/u"])
     assert np.allclose(dx, g[f"{name}/fwd_dx"], rtol=1e-10, atol=1e-12) and np.allclose(H, g[f"{name}/fwd_H"], rtol=1e-10, atol=1e-12)
     xb, ub = m.vjp(g[f"{name}/x"], g[f"{name}/u"], g[f"{name}/lam"])
-    assert ub.shape == (64, 2)
+    assert ub.shape == (64, nu)
     assert np.allclose(xb, g[f"{name}/vjp_xbar"], rtol=1e-9, atol=1e-11) and np.allclose(ub, g[f"{name}/vjp_ubar"], rtol=1e-9, atol=1e-11)
-    cost = _capi.make_cost(4, 2, g[f"{name}/Q"], g[f"{name}/R"], None, -10.0, 10.0)
+    cost = _capi.make_cost(4, nu, g[f"{name}/Q"], g[f"{name}/R"], None, -10.0, 10.0)
     for integ in ("euler", "rk4"):
         r = m.rollout(g[f"{name}/roll_x0"], g[f"{name}/roll_U"], cost, integ, 0.02)
         assert np.allclose(r["traj"], g[f"{name}/roll_{integ}_traj"], rtol=1e-9, atol=1e-11)
         assert np.allclose(r["cost"], g[f"{name}/roll_{integ}_cost"], rtol=1e-9)
         ref = g[f"{name}/roll_{integ}_gu"]
-        assert r["grad_u"].shape == ref.shape == (6, 30, 2)
+        assert r["grad_u"].shape == ref.shape == (6, 30, nu)
         assert np.abs(r["grad_u"] - ref).max() <= 1e-9 * np.abs(ref).max()
         assert np.abs(r["grad_x0"] - g[f"{name}/roll_{integ}_gx0"]).max() <= 1e-9 * np.abs(g[f"{name}/roll_{integ}_gx0"]).max()
         U = g[f"{name}/roll_U"]
