@@ -87,3 +87,33 @@ def test_training_step_on_gpu_parameters_uses_the_device_packer(torch, monkeypat
             assert calls["dev"] == 3 and calls["host"] == 0, calls
     assert calls["host"] == 3
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+NAMED = ([("golden_m2.npz", n) for n in ol.M2_MODELS] + [("golden_m34.npz", n) for n in ("phnn_m3_fix", "phnn_m4_gnet", "canonical_m3")] +
+         [("golden_mass.npz", n) for n in ol.MASS_TYPES])
+
+
+@pytest.mark.parametrize("fname,name", NAMED)
+def test_device_packed_image_equals_host_packed_multi_input_and_mass_models(torch, fname, name):
+    """The same for the models with several control inputs (G is (n, m)) and the MassMatrixNetwork variants (mass constants /
+    M_net.mlp in the image)."""
+    from phnn_mpc_amd import weights
+    from phnn_mpc_amd.engine import RolloutEngine
+    _, ws = ol.load_named_golden(fname)
+    w = ws[name]
+    eng = RolloutEngine(w)
+    rng = np.random.default_rng(11)
+    for scale in (0.0, 0.05):
+        w2 = perturbed(w, rng, scale)
+        _, blob = weights.pack_state_dict(w2, kind=eng.kind)
+        eng.update_weights(w2)
+        host = eng.read_image()
+        eng.update_weights(w)
+        eng.update_weights_dev(torch.tensor(blob, device=eng.device))
+        dev = eng.read_image()
+        diff = np.flatnonzero(host.view(np.uint32) != dev.view(np.uint32))
+        if eng.kind == 1:  # canonical: the libm-dependent constants (softplus / sigmoid of R_diag_raw, mass constants)
+            assert diff.size <= 14, (name, scale, diff.size)
+            assert np.allclose(host[diff], dev[diff], rtol=2.5e-7, atol=0.0)
+        else:
+            assert diff.size == 0, (name, scale, diff[:8])
