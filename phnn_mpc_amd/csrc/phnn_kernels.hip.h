@@ -879,16 +879,25 @@ struct WRec {
   static constexpr int SIZE = oSmall + 16 * kRecSmall;
 };
 
-// plain (cached) store: the reduce kernel reads the record back soon, possibly from the Infinity Cache
+// The record stream is written once by the adjoint march and read once by k_wgrad_reduce (3.8 GB at the bench shape):
+// non-temporal stores and loads.  Round 3, B = 65 536, H = 50: the record-writing adjoint 1.71 -> 1.55 ms, the reduction
+// 2.90 -> 2.95 ms, the training pass 5.42 -> 5.31 ms.  (PHNN_CACHED_RECORDS: plain accesses.)
+#ifdef PHNN_CACHED_RECORDS
+#define PHNN_REC_STORE(v, p) (*(p) = (v))
+#define PHNN_REC_LOAD(p) (*(p))
+#else
+#define PHNN_REC_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#define PHNN_REC_LOAD(p) __builtin_nontemporal_load((p))
+#endif
 template <int T>
 DEV void store_rec(float* dst, Lane ln, const Act<T>& a) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) reinterpret_cast<f32x4*>(dst)[t * 64 + ln.lane] = a.v[t];
+  for (int t = 0; t < T; ++t) PHNN_REC_STORE(a.v[t], reinterpret_cast<f32x4*>(dst) + t * 64 + ln.lane);
 }
 template <int T>
 DEV void store_rec_scaled(float* dst, Lane ln, const Act<T>& a, float s) {
 #pragma unroll
-  for (int t = 0; t < T; ++t) reinterpret_cast<f32x4*>(dst)[t * 64 + ln.lane] = a.v[t] * s;
+  for (int t = 0; t < T; ++t) PHNN_REC_STORE(a.v[t] * s, reinterpret_cast<f32x4*>(dst) + t * 64 + ln.lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1168,7 +1177,7 @@ DEV f32x4 hnet_hvp(const float* L, Lane ln, HTape<HID>& tp, f32x4 v, float* rec 
     f32x4 w3 = *reinterpret_cast<const f32x4*>(L + Y::oW3S + 16 * t + 4 * ln.q);  // w3 / S: w holds S * zdot2
     f32x4 a2 = tp.a2.v[t];
     f32x4 ad2 = dtanh(a2) * w.v[t];
-    if (WG) reinterpret_cast<f32x4*>(rec + 2 * T * 256)[t * 64 + ln.lane] = ad2 * unscale;
+    if (WG) PHNN_REC_STORE(ad2 * unscale, reinterpret_cast<f32x4*>(rec + 2 * T * 256) + t * 64 + ln.lane);
     w.v[t] = w3 * (a2 * ad2);  // -gdot2 / 2
   }
   Act<T> qd;
@@ -3140,7 +3149,7 @@ struct RecSlice {
     const f32x4* bg = reinterpret_cast<const f32x4*>(R) + w * 64 + ln.lane;
     const f32x4* tg = reinterpret_cast<const f32x4*>(tape) + w * 64 + ln.lane;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) big[k] = (tape && k < 2) ? tg[k * vec4] : bg[k * vec4];
+    for (int k = 0; k < NB; ++k) big[k] = (tape && k < 2) ? PHNN_REC_LOAD(tg + k * vec4) : PHNN_REC_LOAD(bg + k * vec4);
     const f32x4* s4 = reinterpret_cast<const f32x4*>(R + oSmall + ln.i * kRecSmall);
     x = s4[0];
     v = s4[1];
